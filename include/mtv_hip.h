@@ -1,0 +1,126 @@
+/*
+ * mtv_hip.h -- C ABI of libmtv_hip.so: the MI355X (gfx950) denoising step of MoDiTalker's MToV
+ * latent-video diffusion sampler (tri-plane UNet forward + eta=1 DDIM update) as hand-written HIP.
+ *
+ * The reference has NO FFI / plugin interface for this path: its boundary is three Python classes
+ * (SURVEY.md section 8b).  This header is therefore the build's own C boundary *under* the Python
+ * look-alikes in moditalker_amd/{unet,ddpm}.py; each entry point cites the reference code whose
+ * work it replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers are raw `float*` / `int64_t*` (Tensor.data_ptr()),
+ *     BORROWED for the duration of the call (the caller keeps ownership and keeps them alive until
+ *     the stream has drained); sizes are ints.
+ *   - every function returns MTV_OK (0) or a negative error code; mtv_last_error() gives the text
+ *     of the last failure on the calling thread.  No C++ exception crosses the ABI.
+ *   - a context is bound to the HIP device that was current at mtv_create() and is NOT re-entrant:
+ *     one caller at a time, launches go to the `stream` argument (pass torch's current stream so
+ *     torch ordering holds).  `stream` is a hipStream_t passed as void*.
+ *   - all tensors fp32.  External activations use the reference's layout, channel-major
+ *     [B, C, L] with L = R*R + 2*T*R (xy plane | yt plane | xt plane, unet.py:1027-1029).
+ */
+#ifndef MTV_HIP_H
+#define MTV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTV_OK 0
+#define MTV_ERR_INVALID (-1)     /* bad argument / unsupported configuration */
+#define MTV_ERR_HIP (-2)         /* a HIP runtime call failed                 */
+#define MTV_ERR_WEIGHT (-3)      /* unknown key, wrong shape, or weights missing at forward time */
+#define MTV_ERR_STATE (-4)       /* call sequence error (e.g. batch > max_batch) */
+#define MTV_IGNORED 1            /* mtv_load_weight: key accepted but unused (output_bg_*) */
+
+#define MTV_MAX_LEVELS 8
+
+/* UNet hyper-parameters: the subset of UNetModel.__init__ kwargs (unet.py:631-659) the hot path
+ * depends on, plus the tri-plane geometry the reference hard-wires to (32,16) (unet.py:1027-1029). */
+typedef struct mtv_config {
+    int32_t model_channels;                       /* unet_config.model_channels (128)            */
+    int32_t num_res_blocks;                       /* (2)                                         */
+    int32_t num_heads;                            /* (8) heads in every attention block          */
+    int32_t n_levels;                             /* len(channel_mult)                           */
+    int32_t channel_mult[MTV_MAX_LEVELS];         /* ([1,2,4,4])                                 */
+    int32_t n_attention_resolutions;
+    int32_t attention_resolutions[MTV_MAX_LEVELS];/* ([4,2,1]) downsample rates with 2-D attention */
+    int32_t use_scale_shift_norm;                 /* (1) FiLM: GN(h)*(1+s)+b ; 0: h+emb then GN  */
+    int32_t out_channels;                         /* (4)                                         */
+    int32_t res;                                  /* R: xy plane is R x R                        */
+    int32_t frames;                               /* T: yt / xt planes are T x R                 */
+    int32_t max_batch;                            /* workspace is sized for this many clips      */
+} mtv_config;
+
+typedef struct mtv_ctx mtv_ctx;
+
+const char* mtv_last_error(void);
+int mtv_version(void);
+
+/* Replaces UNetModel.__init__ (unet.py:631-975): builds the block list, allocates the
+ * token-major channels-last workspace [B, L, C] per tensor and the im2col gather tables. */
+int mtv_create(const mtv_config* cfg, mtv_ctx** out);
+int mtv_destroy(mtv_ctx* ctx);
+
+/* Checkpoint interface -- replaces `load_state_dict` (sample.py:229-230).
+ * Keys are the reference's state_dict names WITHOUT the `diffusion_model.` prefix, e.g.
+ * "input_blocks.4.0.in_layers.2.weight" [256,128,3,3].  `data` may be a host or a device pointer
+ * (fp32, contiguous, PyTorch layout: OIHW conv, [O,I,1] conv1d, [O,I] linear); the library repacks
+ * into its device layout ([tap][Cin][Cout] etc.).  Keys under output_bg_blocks./output_bg_attns.
+ * (dead in the reference forward, unet.py:859-968) are accepted and return MTV_IGNORED. */
+int mtv_num_weights(const mtv_ctx* ctx);
+int mtv_weight_info(const mtv_ctx* ctx, int index, char* key_out, int key_cap, int* ndim_out, int64_t shape_out[4]);
+int mtv_load_weight(mtv_ctx* ctx, const char* key, const float* data, int ndim, const int64_t* shape);
+int mtv_weights_missing(const mtv_ctx* ctx);   /* number of required keys not loaded yet */
+
+/* Replaces UNetModel.forward / DiffusionWrapper.forward (unet.py:995-1117, 41-44):
+ *   x [B,4,L], cond [B,8,L], image_cond [B,4,image_cond_len] (only the first R*R tokens are
+ *   used, the yt/xt planes of image_cond are zeros: unet.py:1022-1025), timesteps [B] int64 on the
+ *   device, eps_out [B,out_channels,L].  All device pointers. */
+int mtv_forward(mtv_ctx* ctx, const float* x, const float* cond, const float* image_cond,
+                int image_cond_len, const int64_t* timesteps, float* eps_out, int batch, void* stream);
+
+/* One entry per DDIM step, computed by the host exactly as ddpm.py:390-394 does (fp32). */
+typedef struct mtv_ddim_step {
+    int32_t t;                 /* timestep fed to the UNet (ddpm.py:383)                          */
+    int32_t last;              /* 1: time_next < 0 -> result is clamped x0 (ddpm.py:386-388)      */
+    float sqrt_recip_ac;       /* sqrt(1/alphas_cumprod[t])        (ddpm.py:278-282)              */
+    float sqrt_recipm1_ac;     /* sqrt(1/alphas_cumprod[t] - 1)                                   */
+    float sqrt_ac_next;        /* alphas_cumprod[t_next].sqrt()    (ddpm.py:398)                  */
+    float c;                   /* (1 - alpha_next - sigma^2).sqrt()                               */
+    float sigma;               /* eta * ((1-a/a_next)(1-a_next)/(1-a)).sqrt()                     */
+    int32_t noise_index;       /* which [B,4,L] slab of `noise` this step adds (-1: none)         */
+} mtv_ddim_step;
+
+/* Replaces the loop body of DDPM.ddim_sample / ddim_sample_noised_start (ddpm.py:382-398,
+ * 434-448) for `n_steps` consecutive steps: eps = UNet(x_t, cond, image_cond, t);
+ * x0 = clamp(sqrt_recip*x_t - sqrt_recipm1*eps, -1, 1); x <- x0*sqrt_ac_next + c*eps + sigma*noise.
+ *   x_io      [B,4,L]  in: x_T (or the q_sample'd start); out: the clamped x0 of the last step
+ *   noise     [n_noise,B,4,L] explicit N(0,1) draws (the reference draws them from torch's global
+ *             generator inside the loop; the Python wrapper owns that RNG)
+ * The whole step is replayed as one hipGraph per step; steps are device-resident (no host sync). */
+int mtv_ddim_sample(mtv_ctx* ctx, float* x_io, const float* cond, const float* image_cond,
+                    int image_cond_len, const float* noise, int n_noise,
+                    const mtv_ddim_step* steps, int n_steps, int batch, void* stream);
+
+/* Test/debug: copy an internal activation (token-major [B, L_level, C]) to `dst` (device or host).
+ * Names: "in<i>", "mid", "out<i>" = result after the cross-plane attention of that stage. */
+int mtv_debug_tap(mtv_ctx* ctx, const char* name, float* dst, int64_t dst_cap_floats, int* tokens_out, int* channels_out);
+
+/* Introspection for bench.py / DESIGN.md: algorithmic work of one forward at batch 1. */
+typedef struct mtv_work {
+    double flops_conv3x3, flops_1x1, flops_attn_core, flops_linear;
+    double bytes_weights_conv, bytes_weights_other, bytes_act_conv_path;
+    int32_t n_launches;
+} mtv_work;
+int mtv_get_work(const mtv_ctx* ctx, mtv_work* out);
+
+/* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
+int mtv_set_eager(mtv_ctx* ctx, int eager);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTV_HIP_H */

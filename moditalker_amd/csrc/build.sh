@@ -1,0 +1,11 @@
+#!/bin/bash
+# Build libmtv_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function"
+$HIPCC $FLAGS -c kernels.hip -o kernels.o "$@" &
+$HIPCC $FLAGS -c plan.hip -o plan.o "$@" &
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC kernels.o plan.o -o libmtv_hip.so
+echo "built $(pwd)/libmtv_hip.so"

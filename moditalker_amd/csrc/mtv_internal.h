@@ -1,0 +1,118 @@
+// Internal declarations shared by kernels.hip (device code + launchers) and plan.hip (host plan,
+// weights, graph capture, C ABI).  gfx950 only; no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mtv {
+
+// Plane boundaries inside one batch element's token axis: [0,b1) xy (r x r), [b1,b2) yt (t x r),
+// [b2,L) xt (t x r)  -- MToV/models/ddpm/unet.py:1027-1029 generalised to (R>>lvl, T>>lvl).
+struct SegInfo {
+    int b1, b2, L;
+};
+
+// Consumer-side GroupNorm description: statistics live in a per-site table of fp64 (sum, sumsq)
+// per (batch, plane, group); the consumer turns them into per-channel affine coefficients.
+struct GnIn {
+    const double* sums;   // [B][3][32][2] or nullptr (no normalisation)
+    const float* gamma;   // [Cmain]
+    const float* beta;    // [Cmain]
+    const float* film;    // per batch: scale at [c], shift at [Cmain + c]; nullptr = none
+    int film_stride;      // floats between batch elements of `film`
+    int gs;               // channels per group = Cmain / 32
+    int whole;            // 1: statistics over all L tokens (AttentionBlock1D); 0: per plane
+    int act;              // 1: SiLU after the affine
+};
+
+struct ConvArgs {
+    const float* src[4];  // parts [0,nmain): tapped sources (concatenated along channels);
+    int C[4];             //       [nmain, nmain+nskip): raw sources of the fused 1x1 skip conv
+    int nmain, nskip;
+    int Cmain, Cskip;
+    const int* gather;       // [ntaps][Lout] source token per (tap, output token), -1 = zero pad; nullptr = identity
+    const int* gather_skip;  // [Lout] source token for skip parts / residual; nullptr = identity
+    int ntaps;
+    int Lout, Lsrc, Lskip;   // tokens per batch element: output, tapped source, skip/residual source
+    int B;
+    const float* W;          // rows [ntaps*Cmain + Cskip][ldw], columns = output channels
+    int ldw;
+    int N;
+    const float* bias;       // [N]
+    const float* bias2;      // [N] or nullptr (bias of the fused skip conv)
+    const float* bias_b;     // per-batch additive [B][bias_b_stride] or nullptr
+    int bias_b_stride;
+    GnIn gn;
+    SegInfo seg_src;         // plane boundaries of the tapped source token axis
+    const float* res;        // residual [B][Lskip][N] (identity skip) or nullptr
+    float* out;
+    int out_cm;              // 1: write channel-major [B][N][Lout] (the external layout)
+};
+
+struct StatsArgs {
+    const float* src[2];
+    int C[2];
+    int nparts;
+    int Ctot, gs;
+    int B;
+    SegInfo seg;
+    double* sums;            // [B][3][32][2], pre-zeroed
+};
+
+struct PoolArgs {            // ResBlock(down=True): avgpool2x2 of SiLU(GN(x)) and of x (unet.py:179-184)
+    const float* x;          // [B][Lsrc][C]
+    float* out_act;          // [B][Ldst][C]
+    float* out_x;            // [B][Ldst][C]
+    const double* sums;
+    const float* gamma;
+    const float* beta;
+    int B, C, gs;
+    SegInfo seg_src, seg_dst;
+    int r_dst, t_dst;        // destination plane geometry: xy r_dst x r_dst, yt/xt t_dst x r_dst
+};
+
+struct AttnArgs {
+    const float* qkv;        // [B][L][3C], channel = head*3d + {q: 0..d, k: d..2d, v: 2d..3d}
+    float* out;              // [B][L][C], channel = head*d + i
+    int B, L, C, H;
+    int nseg;
+    int seg_start[3], seg_len[3];
+    int tile_prefix[4];      // prefix sums of ceil(seg_len/16)
+    float scale;             // d^-1/4, applied to q AND k (unet.py:322-323)
+};
+
+struct LinearArgs {
+    const float* x;          // [B][K]
+    const float* W;          // [N][K]
+    const float* bias;       // [N]
+    float* out;              // [B][out_stride]
+    int B, K, N, out_stride;
+    int act_in;              // 0 none, 1 SiLU on the input
+};
+
+struct DdimStep {            // mirror of mtv_ddim_step (include/mtv_hip.h)
+    int32_t t, last;
+    float sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_next, c, sigma;
+    int32_t noise_index;
+};
+
+// ---- launchers (kernels.hip) ----
+struct ConvTile { int MT, NT, NW; };
+ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks);
+size_t conv_smem_bytes(const ConvArgs& a, ConvTile t);
+hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s);
+hipError_t conv_init_attrs();
+hipError_t launch_gn_stats(const StatsArgs& a, hipStream_t s);
+hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s);
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+hipError_t launch_linear(const LinearArgs& a, hipStream_t s);
+hipError_t launch_time_sinusoid(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
+hipError_t launch_pack_input(const float* x, const float* cond, const float* image_cond, int ic_len,
+                             float* out, int B, int L, int RR, hipStream_t s);
+hipError_t launch_ddim_update(float* x, const float* eps, const float* noise, const DdimStep* steps,
+                              const int* counter, int64_t n_per_draw, int64_t n, hipStream_t s);
+hipError_t launch_ddim_advance(const DdimStep* steps, int* counter, int n_steps, int64_t* tbuf, int B, hipStream_t s);
+hipError_t launch_ddim_init(const DdimStep* steps, int* counter, int64_t* tbuf, int B, hipStream_t s);
+hipError_t launch_repack_conv(const float* src, float* dst, int N, int C, int ntaps, int ld, hipStream_t s);
+
+}  // namespace mtv

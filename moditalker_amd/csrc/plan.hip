@@ -1,0 +1,1008 @@
+// Host side of libmtv_hip.so: UNet block list -> launch plan, weight repacking, workspace,
+// hipGraph capture of the denoising step, and the C ABI of include/mtv_hip.h.
+//
+// Structure follows what MToV/models/ddpm/unet.py:710-975 constructs and :995-1117 executes, but
+// the plan is MI355X-first: one token-major channels-last buffer per activation, planes batched in
+// every launch, skip concatenations expressed as two-source K loops, timestep FiLM for all
+// ResBlocks in one GEMV, the whole step replayed as one hipGraph with a device-side step counter.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mtv_hip.h"
+#include "mtv_internal.h"
+
+using namespace mtv;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(MTV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));              \
+    } while (0)
+
+namespace {
+
+struct Level {
+    int r, t, L, b1, b2;
+    SegInfo seg() const { return SegInfo{b1, b2, L}; }
+};
+
+enum Role { ROLE_COPY = 0, ROLE_CONV = 1 };
+
+struct WSlot {
+    std::string key;
+    std::vector<int64_t> shape;
+    Role role;
+    float* dst;
+    int ld;         // ROLE_CONV: leading dimension (padded output channels)
+    bool loaded;
+};
+
+struct Tens {
+    float* p = nullptr;
+    int C = 0;
+    int lvl = 0;
+};
+
+struct ResDesc {
+    int cin, cout, updown;   // updown: 0 none, 1 down, 2 up
+    int film_off;
+};
+struct Layer {
+    int type;                // 0 stem conv, 1 resblock, 2 attention (2-D, per plane)
+    ResDesc res;
+    int c;
+    std::string pre;
+};
+struct Stage {
+    std::vector<Layer> layers;
+    int attn1_c = 0;         // channels of the cross-plane AttentionBlock1D after the stage (0: Identity)
+    std::string attn1_pre;
+    std::string tap;
+};
+
+struct Op {
+    std::function<hipError_t(hipStream_t)> run;
+    std::string name;
+};
+
+struct Plan {
+    int B = 0;
+    std::vector<Op> ops;           // UNet forward
+    hipGraphExec_t g_forward = nullptr;
+};
+
+}  // namespace
+
+struct mtv_ctx {
+    mtv_config cfg{};
+    int device = 0;
+    std::vector<Level> lv;
+    std::vector<Stage> inputs, outputs;
+    Stage middle;
+    int film_total = 0;
+    int n_sites = 0;
+    int emb_dim = 0;
+
+    std::vector<WSlot> slots;
+    std::map<std::string, int> slot_index;
+    std::map<std::string, float*> bufs;         // named activation / weight buffers
+    std::map<std::string, std::pair<int, int>> taps;   // tap name -> (level, C) ; buffer = bufs["tap." + name]
+    std::vector<void*> allocs;
+    std::vector<int*> g3, gup3, gup1;           // gather tables per level
+    double* stats = nullptr;                     // GN site arena
+    size_t stats_bytes = 0;
+    int site_cursor = 0;
+    float* freqs = nullptr;
+    // external-layout staging (channel-major) and sampler state
+    float *xin = nullptr, *condin = nullptr, *icin = nullptr, *eps = nullptr;
+    int64_t* tbuf = nullptr;
+    DdimStep* d_steps = nullptr;
+    int d_steps_cap = 0;
+    int* d_counter = nullptr;
+    std::map<int, std::unique_ptr<Plan>> plans;
+    hipStream_t cap_stream = nullptr;
+    bool eager = false;
+    mtv_work work{};
+    bool accounting = false;
+    float* staging = nullptr;
+    size_t staging_floats = 0;
+
+    // ---------------------------------------------------------------- memory helpers
+    int dmalloc(void** p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        allocs.push_back(*p);
+        return MTV_OK;
+    }
+    float* buf(const std::string& name, size_t floats) {
+        auto it = bufs.find(name);
+        if (it != bufs.end()) return it->second;
+        void* p = nullptr;
+        if (dmalloc(&p, floats * sizeof(float)) != MTV_OK) return nullptr;
+        hipMemset(p, 0, floats * sizeof(float));
+        bufs[name] = (float*)p;
+        return (float*)p;
+    }
+    float* act(const std::string& name, int lvl, int C) {   // [max_batch][L_lvl][C]
+        return buf("act." + name, (size_t)cfg.max_batch * lv[lvl].L * C);
+    }
+    WSlot* slot(const std::string& key, std::vector<int64_t> shape, Role role, float* dst, int ld) {
+        auto it = slot_index.find(key);
+        if (it != slot_index.end()) return &slots[it->second];
+        slots.push_back(WSlot{key, std::move(shape), role, dst, ld, false});
+        slot_index[key] = (int)slots.size() - 1;
+        return &slots.back();
+    }
+    // plain-copied vector / matrix parameter
+    float* wcopy(const std::string& key, std::vector<int64_t> shape) {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        float* p = buf("w." + key, n);
+        slot(key, shape, ROLE_COPY, p, 0);
+        return p;
+    }
+    double* new_site() {
+        double* p = stats + (size_t)site_cursor * cfg.max_batch * 192;
+        ++site_cursor;
+        return p;
+    }
+};
+
+// =====================================================================================
+// structure (mirrors unet.py:710-975 for dims=2, resblock_updown=True, legacy attention)
+// =====================================================================================
+static int build_structure(mtv_ctx* c) {
+    const mtv_config& f = c->cfg;
+    const int mc = f.model_channels;
+    auto has_attn = [&](int ds) {
+        for (int i = 0; i < f.n_attention_resolutions; ++i)
+            if (f.attention_resolutions[i] == ds) return true;
+        return false;
+    };
+    int film = 0;
+    auto res_layer = [&](int cin, int cout, int updown, const std::string& pre) {
+        Layer l;
+        l.type = 1;
+        l.res = ResDesc{cin, cout, updown, film};
+        l.c = cout;
+        l.pre = pre;
+        film += f.use_scale_shift_norm ? 2 * cout : cout;
+        return l;
+    };
+    auto attn_layer = [&](int ch, const std::string& pre) {
+        Layer l;
+        l.type = 2;
+        l.res = ResDesc{0, 0, 0, 0};
+        l.c = ch;
+        l.pre = pre;
+        return l;
+    };
+    std::vector<int> chans;
+    {
+        Stage s;
+        Layer l;
+        l.type = 0;
+        l.res = ResDesc{16, mc, 0, 0};
+        l.c = mc;
+        l.pre = "input_blocks.0.0.";
+        s.layers.push_back(l);
+        s.tap = "in0";
+        c->inputs.push_back(s);
+        chans.push_back(mc);
+    }
+    int ch = mc, ds = 1;
+    for (int level = 0; level < f.n_levels; ++level) {
+        const int mult = f.channel_mult[level];
+        for (int k = 0; k < f.num_res_blocks; ++k) {
+            const int idx = (int)c->inputs.size();
+            Stage s;
+            const std::string pre = "input_blocks." + std::to_string(idx) + ".";
+            s.layers.push_back(res_layer(ch, mult * mc, 0, pre + "0."));
+            ch = mult * mc;
+            if (has_attn(ds)) s.layers.push_back(attn_layer(ch, pre + "1."));
+            s.attn1_c = ch;
+            s.attn1_pre = "input_attns." + std::to_string(idx) + ".";
+            s.tap = "in" + std::to_string(idx);
+            c->inputs.push_back(s);
+            chans.push_back(ch);
+        }
+        if (level != f.n_levels - 1) {
+            const int idx = (int)c->inputs.size();
+            Stage s;
+            s.layers.push_back(res_layer(ch, ch, 1, "input_blocks." + std::to_string(idx) + ".0."));
+            s.attn1_c = ch;
+            s.attn1_pre = "input_attns." + std::to_string(idx) + ".";
+            s.tap = "in" + std::to_string(idx);
+            c->inputs.push_back(s);
+            chans.push_back(ch);
+            ds *= 2;
+        }
+    }
+    c->middle.layers.push_back(res_layer(ch, ch, 0, "middle_block.0."));
+    c->middle.layers.push_back(attn_layer(ch, "middle_block.1."));
+    c->middle.layers.push_back(res_layer(ch, ch, 0, "middle_block.2."));
+    c->middle.attn1_c = ch;
+    c->middle.attn1_pre = "mid_attn.";
+    c->middle.tap = "mid";
+    for (int level = f.n_levels - 1; level >= 0; --level) {
+        const int mult = f.channel_mult[level];
+        for (int i = 0; i <= f.num_res_blocks; ++i) {
+            const int ich = chans.back();
+            chans.pop_back();
+            const int idx = (int)c->outputs.size();
+            Stage s;
+            const std::string pre = "output_blocks." + std::to_string(idx) + ".";
+            int j = 0;
+            s.layers.push_back(res_layer(ch + ich, mc * mult, 0, pre + std::to_string(j++) + "."));
+            ch = mc * mult;
+            if (has_attn(ds)) s.layers.push_back(attn_layer(ch, pre + std::to_string(j++) + "."));
+            if (level && i == f.num_res_blocks) {
+                s.layers.push_back(res_layer(ch, ch, 2, pre + std::to_string(j++) + "."));
+                ds /= 2;
+            }
+            s.attn1_c = ch;
+            s.attn1_pre = "output_attns." + std::to_string(idx) + ".";
+            s.tap = "out" + std::to_string(idx);
+            c->outputs.push_back(s);
+        }
+    }
+    c->film_total = film;
+    int nres = 0, nattn = 0;
+    auto count = [&](const Stage& s) {
+        for (auto& l : s.layers) {
+            if (l.type == 1) ++nres;
+            if (l.type == 2) ++nattn;
+        }
+        if (s.attn1_c) ++nattn;
+    };
+    for (auto& s : c->inputs) count(s);
+    count(c->middle);
+    for (auto& s : c->outputs) count(s);
+    c->n_sites = 2 * nres + nattn + 1;
+    return MTV_OK;
+}
+
+// im2col gather tables: source token per (tap, output token) within one batch element, -1 = pad.
+static void plane_geom(const Level& l, int p, int& h, int& w, int& off) {
+    if (p == 0) { h = l.r; w = l.r; off = 0; }
+    else if (p == 1) { h = l.t; w = l.r; off = l.b1; }
+    else { h = l.t; w = l.r; off = l.b2; }
+}
+
+static std::vector<int> make_gather3(const Level& dst, const Level& src, bool up) {
+    std::vector<int> g((size_t)9 * dst.L, -1);
+    for (int p = 0; p < 3; ++p) {
+        int h, w, off, hs, ws, offs;
+        plane_geom(dst, p, h, w, off);
+        plane_geom(src, p, hs, ws, offs);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x)
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int yy = y + ky - 1, xx = x + kx - 1;
+                        if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                        const int sy = up ? yy >> 1 : yy, sx = up ? xx >> 1 : xx;
+                        g[(size_t)(ky * 3 + kx) * dst.L + off + y * w + x] = offs + sy * ws + sx;
+                    }
+    }
+    return g;
+}
+
+static std::vector<int> make_gather_up1(const Level& dst, const Level& src) {
+    std::vector<int> g((size_t)dst.L, -1);
+    for (int p = 0; p < 3; ++p) {
+        int h, w, off, hs, ws, offs;
+        plane_geom(dst, p, h, w, off);
+        plane_geom(src, p, hs, ws, offs);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) g[off + y * w + x] = offs + (y >> 1) * ws + (x >> 1);
+    }
+    return g;
+}
+
+// =====================================================================================
+// plan builder
+// =====================================================================================
+namespace {
+
+struct Builder {
+    mtv_ctx* c;
+    Plan* plan;
+    int B;
+    const mtv_config& f;
+    int emb;
+    float* film_out;     // [maxB][film_total]
+    std::string err;
+
+    Builder(mtv_ctx* ctx, Plan* p, int batch) : c(ctx), plan(p), B(batch), f(ctx->cfg), emb(ctx->emb_dim), film_out(nullptr) {}
+
+    void push(const std::string& name, std::function<hipError_t(hipStream_t)> fn) { plan->ops.push_back(Op{std::move(fn), name}); }
+
+    // ---- weights ----
+    // conv weight (3x3 or 1x1 / conv1d) repacked to [tap][Cin][ld]; `dst`/`ld` given when it shares a fused buffer
+    void wconv(const std::string& key, int N, int C, int kh, int kw, bool conv1d, float* dst, int ld) {
+        std::vector<int64_t> shape;
+        if (conv1d) shape = {N, C, 1};
+        else shape = {N, C, kh, kw};
+        c->slot(key, shape, ROLE_CONV, dst, ld);
+    }
+    static int pad64(int n) { return (n + 63) / 64 * 64; }
+
+    void account_conv(const ConvArgs& a) {
+        if (!c->accounting) return;
+        const double m = (double)a.Lout;   // per batch element
+        c->work.flops_conv3x3 += a.ntaps == 9 ? 2.0 * m * a.N * 9.0 * a.Cmain : 0.0;
+        c->work.flops_1x1 += (a.ntaps == 1 ? 2.0 * m * a.N * a.Cmain : 0.0) + 2.0 * m * a.N * a.Cskip;
+        const double wbytes = 4.0 * ((double)a.ntaps * a.Cmain + a.Cskip) * a.N + 4.0 * a.N;
+        if (a.ntaps == 9) {
+            c->work.bytes_weights_conv += wbytes;
+            // activations of the fused conv/GN path: read the tapped source once, write the output once
+            c->work.bytes_act_conv_path += 4.0 * ((double)a.Lsrc * a.Cmain + (double)a.Lout * a.N + (double)a.Lskip * a.Cskip +
+                                                  (a.res ? (double)a.Lout * a.N : 0.0));
+        } else {
+            c->work.bytes_weights_other += wbytes;
+        }
+    }
+
+    void add_conv(ConvArgs a, const std::string& name) {
+        a.B = B;
+        const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
+        const ConvTile t = conv_pick_tile(B, a.Lout, a.N, nchunks);
+        account_conv(a);
+        push("conv:" + name, [a, t](hipStream_t s) { return launch_conv(a, t, s); });
+    }
+
+    void add_stats(const std::vector<Tens>& parts, int lvl, double* site) {
+        StatsArgs a{};
+        a.nparts = (int)parts.size();
+        int ct = 0;
+        for (int i = 0; i < a.nparts; ++i) {
+            a.src[i] = parts[i].p;
+            a.C[i] = parts[i].C;
+            ct += parts[i].C;
+        }
+        a.Ctot = ct;
+        a.gs = ct / 32;
+        a.B = B;
+        a.seg = c->lv[lvl].seg();
+        a.sums = site;
+        push("gn_stats", [a](hipStream_t s) { return launch_gn_stats(a, s); });
+    }
+
+    float* gnvec(const std::string& key, int C) { return c->wcopy(key, {C}); }
+
+    // ---- ResBlock (unet.py:93-207) ----
+    Tens resblock(const std::vector<Tens>& x, const Layer& ly, const std::string& nm) {
+        const ResDesc& r = ly.res;
+        const int lvl_in = x[0].lvl;
+        const int lvl_out = r.updown == 1 ? lvl_in + 1 : (r.updown == 2 ? lvl_in - 1 : lvl_in);
+        const Level& Lo = c->lv[lvl_out];
+        const Level& Li = c->lv[lvl_in];
+        const std::string P = ly.pre;
+        int cin = 0;
+        for (auto& t : x) cin += t.C;
+        if (cin != r.cin) { err = "resblock channel mismatch at " + P; return Tens{}; }
+        if ((cin % 32) || (r.cout % 32) || (cin % 16) || (r.cout % 16)) { err = "channels must be multiples of 32 at " + P; return Tens{}; }
+
+        float* g1 = gnvec(P + "in_layers.0.weight", cin);
+        float* b1 = gnvec(P + "in_layers.0.bias", cin);
+        float* cb1 = c->wcopy(P + "in_layers.2.bias", {r.cout});
+        const int ld1 = pad64(r.cout);
+        float* W1 = c->buf("w." + P + "in_layers.2.weight", (size_t)9 * cin * ld1);
+        wconv(P + "in_layers.2.weight", r.cout, cin, 3, 3, false, W1, ld1);
+        const int fdim = f.use_scale_shift_norm ? 2 * r.cout : r.cout;
+        // emb_layers.1 lives inside the concatenated FiLM matrix
+        c->slot(P + "emb_layers.1.weight", {fdim, emb}, ROLE_COPY, c->bufs["w.film"] + (size_t)r.film_off * emb, 0);
+        c->slot(P + "emb_layers.1.bias", {fdim}, ROLE_COPY, c->bufs["w.film_bias"] + r.film_off, 0);
+        float* g2 = gnvec(P + "out_layers.0.weight", r.cout);
+        float* b2 = gnvec(P + "out_layers.0.bias", r.cout);
+        float* cb2 = c->wcopy(P + "out_layers.3.bias", {r.cout});
+        const bool has_skip_conv = cin != r.cout;
+        const int ld2 = pad64(r.cout);
+        float* W2 = c->buf("w." + P + "out_layers.3.weight", (size_t)(9 * r.cout + (has_skip_conv ? cin : 0)) * ld2);
+        wconv(P + "out_layers.3.weight", r.cout, r.cout, 3, 3, false, W2, ld2);
+        float* sb = nullptr;
+        if (has_skip_conv) {
+            wconv(P + "skip_connection.weight", r.cout, cin, 1, 1, false, W2 + (size_t)9 * r.cout * ld2, ld2);
+            sb = c->wcopy(P + "skip_connection.bias", {r.cout});
+        }
+
+        // GN1 statistics of x (per plane)
+        double* site1 = c->new_site();
+        add_stats(x, lvl_in, site1);
+
+        Tens h1;
+        h1.lvl = lvl_out;
+        h1.C = r.cout;
+        h1.p = c->act(nm + ".h1", lvl_out, r.cout);
+        Tens px;   // pooled x (down only)
+        ConvArgs a{};
+        a.ntaps = 9;
+        a.Lout = Lo.L;
+        a.N = r.cout;
+        a.W = W1;
+        a.ldw = ld1;
+        a.bias = cb1;
+        a.out = h1.p;
+        a.Cmain = cin;
+        if (!f.use_scale_shift_norm) {        // h = h + emb_out (unet.py:205)
+            a.bias_b = film_out + r.film_off;
+            a.bias_b_stride = c->film_total;
+        }
+        if (r.updown == 1) {
+            if (x.size() != 1) { err = "down block with concat input"; return Tens{}; }
+            Tens pa;
+            pa.lvl = lvl_out; pa.C = cin; pa.p = c->act(nm + ".pool_act", lvl_out, cin);
+            px.lvl = lvl_out; px.C = cin; px.p = c->act(nm + ".pool_x", lvl_out, cin);
+            PoolArgs pl{};
+            pl.x = x[0].p; pl.out_act = pa.p; pl.out_x = px.p; pl.sums = site1; pl.gamma = g1; pl.beta = b1;
+            pl.B = B; pl.C = cin; pl.gs = cin / 32; pl.seg_src = Li.seg(); pl.seg_dst = Lo.seg(); pl.r_dst = Lo.r; pl.t_dst = Lo.t;
+            push("pool_down", [pl](hipStream_t s) { return launch_pool_down(pl, s); });
+            a.nmain = 1; a.src[0] = pa.p; a.C[0] = cin;
+            a.gather = c->g3[lvl_out];
+            a.Lsrc = Lo.L;
+            a.seg_src = Lo.seg();
+        } else {
+            a.nmain = (int)x.size();
+            for (int i = 0; i < a.nmain; ++i) { a.src[i] = x[i].p; a.C[i] = x[i].C; }
+            a.gather = r.updown == 2 ? c->gup3[lvl_out] : c->g3[lvl_out];
+            a.Lsrc = Li.L;
+            a.seg_src = Li.seg();
+            a.gn = GnIn{site1, g1, b1, nullptr, 0, cin / 32, 0, 1};
+        }
+        add_conv(a, nm + ".conv1");
+
+        // GN2 statistics of h1
+        double* site2 = c->new_site();
+        add_stats({h1}, lvl_out, site2);
+
+        Tens out;
+        out.lvl = lvl_out;
+        out.C = r.cout;
+        out.p = c->act(nm + ".out", lvl_out, r.cout);
+        ConvArgs d{};
+        d.ntaps = 9;
+        d.Lout = Lo.L;
+        d.Lsrc = Lo.L;
+        d.N = r.cout;
+        d.W = W2;
+        d.ldw = ld2;
+        d.bias = cb2;
+        d.out = out.p;
+        d.nmain = 1;
+        d.src[0] = h1.p;
+        d.C[0] = r.cout;
+        d.Cmain = r.cout;
+        d.gather = c->g3[lvl_out];
+        d.seg_src = Lo.seg();
+        d.gn = GnIn{site2, g2, b2, f.use_scale_shift_norm ? film_out + r.film_off : nullptr, c->film_total, r.cout / 32, 0, 1};
+        if (has_skip_conv) {
+            if (r.updown) { err = "up/down block with skip conv"; return Tens{}; }
+            d.nskip = (int)x.size();
+            for (int i = 0; i < d.nskip; ++i) { d.src[1 + i] = x[i].p; d.C[1 + i] = x[i].C; }
+            d.Cskip = cin;
+            d.Lskip = Li.L;
+            d.bias2 = sb;
+        } else {
+            if (x.size() != 1) { err = "identity skip with concat input"; return Tens{}; }
+            if (r.updown == 1) { d.res = px.p; d.Lskip = Lo.L; }
+            else if (r.updown == 2) { d.res = x[0].p; d.Lskip = Li.L; d.gather_skip = c->gup1[lvl_out]; }
+            else { d.res = x[0].p; d.Lskip = Lo.L; }
+        }
+        add_conv(d, nm + ".conv2");
+        return out;
+    }
+
+    // ---- AttentionBlock / AttentionBlock1D (unet.py:210-300) ----
+    Tens attention(const Tens& x, const std::string& P, bool whole, const std::string& nm) {
+        const int C = x.C, lvl = x.lvl;
+        const Level& L = c->lv[lvl];
+        const int H = f.num_heads;
+        if (C % H || (C / H) % 4 || C % 32) { err = "attention channels/heads unsupported at " + P; return Tens{}; }
+        const int d = C / H;
+        if (!(d == 4 || d == 8 || d == 16 || d == 32 || d == 64 || d == 128)) { err = "head dim unsupported at " + P; return Tens{}; }
+        float* gw = gnvec(P + "norm.weight", C);
+        float* gb = gnvec(P + "norm.bias", C);
+        const int ldq = pad64(3 * C);
+        float* Wq = c->buf("w." + P + "qkv.weight", (size_t)C * ldq);
+        wconv(P + "qkv.weight", 3 * C, C, 1, 1, true, Wq, ldq);
+        float* bq = c->wcopy(P + "qkv.bias", {3 * C});
+        const int ldp = pad64(C);
+        float* Wp = c->buf("w." + P + "proj_out.weight", (size_t)C * ldp);
+        wconv(P + "proj_out.weight", C, C, 1, 1, true, Wp, ldp);
+        float* bp = c->wcopy(P + "proj_out.bias", {C});
+
+        double* site = c->new_site();
+        add_stats({x}, lvl, site);
+        float* qkv = c->act(nm + ".qkv", lvl, 3 * C);
+        ConvArgs a{};
+        a.ntaps = 1; a.Lout = L.L; a.Lsrc = L.L; a.N = 3 * C; a.W = Wq; a.ldw = ldq; a.bias = bq; a.out = qkv;
+        a.nmain = 1; a.src[0] = x.p; a.C[0] = C; a.Cmain = C; a.seg_src = L.seg();
+        a.gn = GnIn{site, gw, gb, nullptr, 0, C / 32, whole ? 1 : 0, 0};
+        add_conv(a, nm + ".qkv");
+
+        float* att = c->act(nm + ".att", lvl, C);
+        AttnArgs t{};
+        t.qkv = qkv; t.out = att; t.B = B; t.L = L.L; t.C = C; t.H = H;
+        t.scale = 1.0f / std::sqrt(std::sqrt((float)d));
+        if (whole) {
+            t.nseg = 1; t.seg_start[0] = 0; t.seg_len[0] = L.L;
+        } else {
+            t.nseg = 3;
+            t.seg_start[0] = 0; t.seg_len[0] = L.b1;
+            t.seg_start[1] = L.b1; t.seg_len[1] = L.b2 - L.b1;
+            t.seg_start[2] = L.b2; t.seg_len[2] = L.L - L.b2;
+        }
+        t.tile_prefix[0] = 0;
+        for (int i = 0; i < t.nseg; ++i) t.tile_prefix[i + 1] = t.tile_prefix[i] + (t.seg_len[i] + 15) / 16;
+        if (c->accounting)
+            for (int i = 0; i < t.nseg; ++i) c->work.flops_attn_core += 4.0 * H * (double)t.seg_len[i] * t.seg_len[i] * d;
+        push("attn:" + nm, [t](hipStream_t s) { return launch_attention(t, s); });
+
+        Tens out;
+        out.lvl = lvl; out.C = C; out.p = c->act(nm + ".out", lvl, C);
+        ConvArgs p{};
+        p.ntaps = 1; p.Lout = L.L; p.Lsrc = L.L; p.Lskip = L.L; p.N = C; p.W = Wp; p.ldw = ldp; p.bias = bp; p.out = out.p;
+        p.nmain = 1; p.src[0] = att; p.C[0] = C; p.Cmain = C; p.seg_src = L.seg();
+        p.res = x.p;
+        add_conv(p, nm + ".proj");
+        return out;
+    }
+
+    Tens run_stage(const Stage& st, std::vector<Tens> x, const std::string& nm) {
+        Tens cur;
+        for (size_t j = 0; j < st.layers.size(); ++j) {
+            const Layer& ly = st.layers[j];
+            const std::string lnm = nm + "." + std::to_string(j);
+            if (ly.type == 0) {
+                // stem conv (unet.py:714): 16 -> model_channels, no norm
+                const int ld = pad64(ly.c);
+                float* W = c->buf("w." + ly.pre + "weight", (size_t)9 * 16 * ld);
+                wconv(ly.pre + "weight", ly.c, 16, 3, 3, false, W, ld);
+                float* bias = c->wcopy(ly.pre + "bias", {ly.c});
+                const Level& L = c->lv[0];
+                cur.lvl = 0; cur.C = ly.c; cur.p = c->act(lnm + ".out", 0, ly.c);
+                ConvArgs a{};
+                a.ntaps = 9; a.Lout = L.L; a.Lsrc = L.L; a.N = ly.c; a.W = W; a.ldw = ld; a.bias = bias; a.out = cur.p;
+                a.nmain = 1; a.src[0] = x[0].p; a.C[0] = 16; a.Cmain = 16; a.gather = c->g3[0]; a.seg_src = L.seg();
+                add_conv(a, lnm);
+            } else if (ly.type == 1) {
+                cur = resblock(x, ly, lnm);
+            } else {
+                cur = attention(x[0], ly.pre, false, lnm);
+            }
+            if (!err.empty()) return Tens{};
+            x = {cur};
+        }
+        if (st.attn1_c) cur = attention(cur, st.attn1_pre, true, nm + ".a1");
+        c->taps[st.tap] = {cur.lvl, cur.C};
+        c->bufs["tap." + st.tap] = cur.p;
+        return cur;
+    }
+
+    int build() {
+        const int mc = f.model_channels;
+        // ---- timestep embedding path (unet.py:1011-1012 and every ResBlock's emb_layers) ----
+        c->buf("w.film", (size_t)c->film_total * emb);
+        c->buf("w.film_bias", (size_t)c->film_total);
+        float* tsin = c->buf("emb.sin", (size_t)f.max_batch * mc);
+        float* e0 = c->buf("emb.e0", (size_t)f.max_batch * emb);
+        float* e1 = c->buf("emb.e1", (size_t)f.max_batch * emb);
+        film_out = c->buf("emb.film", (size_t)f.max_batch * c->film_total);
+        float* W0 = c->wcopy("time_embed.0.weight", {emb, mc});
+        float* B0 = c->wcopy("time_embed.0.bias", {emb});
+        float* W2 = c->wcopy("time_embed.2.weight", {emb, emb});
+        float* B2 = c->wcopy("time_embed.2.bias", {emb});
+        {
+            double* st = c->stats;
+            const size_t nb = c->stats_bytes;
+            push("memset_stats", [st, nb](hipStream_t s) { return hipMemsetAsync(st, 0, nb, s); });
+            const int64_t* tb = c->tbuf;
+            const float* fr = c->freqs;
+            const int Bn = B, half = mc / 2;
+            push("time_sinusoid", [tb, fr, tsin, Bn, half](hipStream_t s) { return launch_time_sinusoid(tb, fr, tsin, Bn, half, s); });
+            LinearArgs l0{tsin, W0, B0, e0, B, mc, emb, emb, 0};
+            push("time_embed.0", [l0](hipStream_t s) { return launch_linear(l0, s); });
+            LinearArgs l2{e0, W2, B2, e1, B, emb, emb, emb, 1};
+            push("time_embed.2", [l2](hipStream_t s) { return launch_linear(l2, s); });
+            LinearArgs lf{e1, c->bufs["w.film"], c->bufs["w.film_bias"], film_out, B, emb, c->film_total, c->film_total, 1};
+            push("film", [lf](hipStream_t s) { return launch_linear(lf, s); });
+            if (c->accounting) {
+                c->work.flops_linear += 2.0 * ((double)mc * emb + (double)emb * emb + (double)emb * c->film_total);
+                c->work.bytes_weights_other += 4.0 * ((double)mc * emb + (double)emb * emb + (double)emb * c->film_total);
+            }
+        }
+        // ---- input assembly (unet.py:1022-1025) ----
+        Tens h0;
+        h0.lvl = 0; h0.C = 16; h0.p = c->act("h0", 0, 16);
+        {
+            const float *xi = c->xin, *ci = c->condin, *ii = c->icin;
+            float* o = h0.p;
+            const int Bn = B, L = c->lv[0].L, RR = c->lv[0].b1;
+            push("pack_input", [xi, ci, ii, o, Bn, L, RR](hipStream_t s) { return launch_pack_input(xi, ci, ii, RR, o, Bn, L, RR, s); });
+        }
+        c->site_cursor = 0;
+        std::vector<Tens> skips;
+        Tens cur = h0;
+        for (size_t i = 0; i < c->inputs.size(); ++i) {
+            cur = run_stage(c->inputs[i], {cur}, "in" + std::to_string(i));
+            if (!err.empty()) return fail(MTV_ERR_INVALID, err);
+            skips.push_back(cur);
+        }
+        cur = run_stage(c->middle, {cur}, "mid");
+        if (!err.empty()) return fail(MTV_ERR_INVALID, err);
+        for (size_t i = 0; i < c->outputs.size(); ++i) {
+            Tens sk = skips.back();
+            skips.pop_back();
+            if (sk.lvl != cur.lvl) return fail(MTV_ERR_INVALID, "skip level mismatch");
+            cur = run_stage(c->outputs[i], {cur, sk}, "out" + std::to_string(i));
+            if (!err.empty()) return fail(MTV_ERR_INVALID, err);
+        }
+        // ---- head (unet.py:971-975, 1103-1112): GN + SiLU + conv3x3 -> eps in the external layout ----
+        {
+            float* gw = gnvec("out.0.weight", cur.C);
+            float* gb = gnvec("out.0.bias", cur.C);
+            const int ld = pad64(f.out_channels);
+            float* W = c->buf("w.out.2.weight", (size_t)9 * cur.C * ld);
+            wconv("out.2.weight", f.out_channels, cur.C, 3, 3, false, W, ld);
+            float* bias = c->wcopy("out.2.bias", {f.out_channels});
+            double* site = c->new_site();
+            add_stats({cur}, 0, site);
+            const Level& L = c->lv[0];
+            ConvArgs a{};
+            a.ntaps = 9; a.Lout = L.L; a.Lsrc = L.L; a.N = f.out_channels; a.W = W; a.ldw = ld; a.bias = bias;
+            a.out = c->eps; a.out_cm = 1;
+            a.nmain = 1; a.src[0] = cur.p; a.C[0] = cur.C; a.Cmain = cur.C; a.gather = c->g3[0]; a.seg_src = L.seg();
+            a.gn = GnIn{site, gw, gb, nullptr, 0, cur.C / 32, 0, 1};
+            add_conv(a, "head");
+        }
+        if (c->site_cursor > c->n_sites) return fail(MTV_ERR_INVALID, "GN site arena overflow");
+        if (c->accounting) c->work.n_launches = (int)plan->ops.size();
+        return MTV_OK;
+    }
+};
+
+}  // namespace
+
+static int get_plan(mtv_ctx* c, int B, Plan** out) {
+    auto it = c->plans.find(B);
+    if (it != c->plans.end()) {
+        *out = it->second.get();
+        return MTV_OK;
+    }
+    std::unique_ptr<Plan> p(new Plan());
+    p->B = B;
+    Builder b(c, p.get(), B);
+    int rc = b.build();
+    if (rc != MTV_OK) return rc;
+    *out = p.get();
+    c->plans[B] = std::move(p);
+    return MTV_OK;
+}
+
+static int run_ops(mtv_ctx* c, Plan* p, hipStream_t s) {
+    for (auto& op : p->ops) {
+        hipError_t e = op.run(s);
+        if (e != hipSuccess) return fail(MTV_ERR_HIP, "launch " + op.name + ": " + hipGetErrorString(e));
+    }
+    return MTV_OK;
+}
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+const char* mtv_last_error(void) { return g_err.c_str(); }
+int mtv_version(void) { return 1; }
+
+int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
+    if (!cfg || !out) return fail(MTV_ERR_INVALID, "null argument");
+    if (cfg->n_levels < 1 || cfg->n_levels > MTV_MAX_LEVELS) return fail(MTV_ERR_INVALID, "n_levels out of range");
+    if (cfg->model_channels % 32) return fail(MTV_ERR_INVALID, "model_channels must be a multiple of 32 (GroupNorm32 + 16-channel K chunks)");
+    if (cfg->max_batch < 1) return fail(MTV_ERR_INVALID, "max_batch < 1");
+    if (cfg->out_channels < 1 || cfg->out_channels > 64) return fail(MTV_ERR_INVALID, "out_channels out of range");
+    const int sh = cfg->n_levels - 1;
+    if (cfg->res % (1 << sh) || cfg->frames % (1 << sh) || (cfg->frames >> sh) < 1 || (cfg->res >> sh) < 1)
+        return fail(MTV_ERR_INVALID, "res/frames must survive len(channel_mult)-1 halvings (SURVEY.md fact 5)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(MTV_ERR_HIP, "no HIP device available");
+    std::unique_ptr<mtv_ctx> c(new mtv_ctx());
+    c->cfg = *cfg;
+    HIPCHK(hipGetDevice(&c->device));
+    c->emb_dim = 4 * cfg->model_channels;
+    for (int l = 0; l < cfg->n_levels; ++l) {
+        Level v;
+        v.r = cfg->res >> l;
+        v.t = cfg->frames >> l;
+        v.b1 = v.r * v.r;
+        v.b2 = v.b1 + v.t * v.r;
+        v.L = v.b2 + v.t * v.r;
+        c->lv.push_back(v);
+    }
+    int rc = build_structure(c.get());
+    if (rc != MTV_OK) return rc;
+    // gather tables
+    for (int l = 0; l < cfg->n_levels; ++l) {
+        auto up = [&](const std::vector<int>& h, int** d) -> int {
+            void* p = nullptr;
+            int r = c->dmalloc(&p, h.size() * sizeof(int));
+            if (r != MTV_OK) return r;
+            if (hipMemcpy(p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(MTV_ERR_HIP, "gather upload");
+            *d = (int*)p;
+            return MTV_OK;
+        };
+        int* d = nullptr;
+        if ((rc = up(make_gather3(c->lv[l], c->lv[l], false), &d)) != MTV_OK) return rc;
+        c->g3.push_back(d);
+        d = nullptr;
+        int* d1 = nullptr;
+        if (l + 1 < cfg->n_levels) {
+            if ((rc = up(make_gather3(c->lv[l], c->lv[l + 1], true), &d)) != MTV_OK) return rc;
+            if ((rc = up(make_gather_up1(c->lv[l], c->lv[l + 1]), &d1)) != MTV_OK) return rc;
+        }
+        c->gup3.push_back(d);
+        c->gup1.push_back(d1);
+    }
+    // statistics arena, staging buffers, sampler state
+    c->stats_bytes = (size_t)c->n_sites * cfg->max_batch * 192 * sizeof(double);
+    if ((rc = c->dmalloc((void**)&c->stats, c->stats_bytes)) != MTV_OK) return rc;
+    const int L = c->lv[0].L, RR = c->lv[0].b1, mb = cfg->max_batch;
+    if ((rc = c->dmalloc((void**)&c->xin, (size_t)mb * 4 * L * 4)) != MTV_OK) return rc;
+    if ((rc = c->dmalloc((void**)&c->condin, (size_t)mb * 8 * L * 4)) != MTV_OK) return rc;
+    if ((rc = c->dmalloc((void**)&c->icin, (size_t)mb * 4 * RR * 4)) != MTV_OK) return rc;
+    if ((rc = c->dmalloc((void**)&c->eps, (size_t)mb * cfg->out_channels * L * 4)) != MTV_OK) return rc;
+    if ((rc = c->dmalloc((void**)&c->tbuf, (size_t)mb * 8)) != MTV_OK) return rc;
+    if ((rc = c->dmalloc((void**)&c->d_counter, 16)) != MTV_OK) return rc;
+    HIPCHK(hipMemset(c->d_counter, 0, 16));
+    {
+        // timestep_embedding frequencies, fp32 like the reference (diffusionmodules.py:118-121)
+        const int half = cfg->model_channels / 2;
+        std::vector<float> fr(half);
+        const float nl = (float)(-std::log(10000.0));
+        for (int k = 0; k < half; ++k) {
+            float v = nl * (float)k;
+            v = v / (float)half;
+            fr[k] = expf(v);
+        }
+        if ((rc = c->dmalloc((void**)&c->freqs, half * 4)) != MTV_OK) return rc;
+        HIPCHK(hipMemcpy(c->freqs, fr.data(), half * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIPCHK(conv_init_attrs());
+    // build the batch-1 plan now: registers every weight slot and fills the work accounting
+    c->accounting = true;
+    Plan* p1 = nullptr;
+    rc = get_plan(c.get(), 1, &p1);
+    c->accounting = false;
+    if (rc != MTV_OK) return rc;
+    *out = c.release();
+    return MTV_OK;
+}
+
+int mtv_destroy(mtv_ctx* c) {
+    if (!c) return MTV_OK;
+    hipDeviceSynchronize();
+    for (auto& kv : c->plans) {
+        if (kv.second->g_forward) hipGraphExecDestroy(kv.second->g_forward);
+    }
+    if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->staging) hipFree(c->staging);
+    if (c->d_steps) hipFree(c->d_steps);
+    delete c;
+    return MTV_OK;
+}
+
+int mtv_num_weights(const mtv_ctx* c) { return c ? (int)c->slots.size() : 0; }
+
+int mtv_weight_info(const mtv_ctx* c, int index, char* key_out, int key_cap, int* ndim_out, int64_t shape_out[4]) {
+    if (!c || index < 0 || index >= (int)c->slots.size()) return fail(MTV_ERR_INVALID, "weight index out of range");
+    const WSlot& s = c->slots[index];
+    if (key_out && key_cap > 0) {
+        std::strncpy(key_out, s.key.c_str(), key_cap - 1);
+        key_out[key_cap - 1] = 0;
+    }
+    if (ndim_out) *ndim_out = (int)s.shape.size();
+    if (shape_out)
+        for (size_t i = 0; i < 4; ++i) shape_out[i] = i < s.shape.size() ? s.shape[i] : 1;
+    return MTV_OK;
+}
+
+int mtv_weights_missing(const mtv_ctx* c) {
+    int n = 0;
+    for (auto& s : c->slots) n += s.loaded ? 0 : 1;
+    return n;
+}
+
+int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, const int64_t* shape) {
+    if (!c || !key || !data || !shape) return fail(MTV_ERR_INVALID, "null argument");
+    std::string k(key);
+    const std::string pre = "diffusion_model.";
+    if (k.compare(0, pre.size(), pre) == 0) k = k.substr(pre.size());
+    if (k.compare(0, 17, "output_bg_blocks.") == 0 || k.compare(0, 16, "output_bg_attns.") == 0) return MTV_IGNORED;
+    auto it = c->slot_index.find(k);
+    if (it == c->slot_index.end()) return fail(MTV_ERR_WEIGHT, "unknown weight key: " + k);
+    WSlot& s = c->slots[it->second];
+    bool ok = ndim == (int)s.shape.size();
+    size_t n = 1;
+    for (int i = 0; ok && i < ndim; ++i) {
+        ok = shape[i] == s.shape[i];
+        n *= (size_t)shape[i];
+    }
+    if (!ok) {
+        std::string m = "shape mismatch for " + k + ": expected [";
+        for (auto d : s.shape) m += std::to_string(d) + ",";
+        m += "] got [";
+        for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + ",";
+        return fail(MTV_ERR_WEIGHT, m + "]");
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (s.role == ROLE_COPY) {
+        HIPCHK(hipMemcpy(s.dst, data, n * sizeof(float), hipMemcpyDefault));
+    } else {
+        if (c->staging_floats < n) {
+            if (c->staging) hipFree(c->staging);
+            c->staging = nullptr;
+            c->staging_floats = 0;
+            HIPCHK(hipMalloc((void**)&c->staging, n * sizeof(float)));
+            c->staging_floats = n;
+        }
+        HIPCHK(hipMemcpy(c->staging, data, n * sizeof(float), hipMemcpyDefault));
+        const int N = (int)s.shape[0], C = (int)s.shape[1];
+        const int ntaps = (int)(n / ((size_t)N * C));
+        HIPCHK(launch_repack_conv(c->staging, s.dst, N, C, ntaps, s.ld, nullptr));
+        HIPCHK(hipStreamSynchronize(nullptr));
+    }
+    s.loaded = true;
+    return MTV_OK;
+}
+
+static int check_ready(mtv_ctx* c, int batch) {
+    if (!c) return fail(MTV_ERR_INVALID, "null context");
+    if (batch < 1 || batch > c->cfg.max_batch) return fail(MTV_ERR_STATE, "batch outside [1, max_batch]");
+    const int miss = mtv_weights_missing(c);
+    if (miss) {
+        std::string first;
+        for (auto& s : c->slots)
+            if (!s.loaded) { first = s.key; break; }
+        return fail(MTV_ERR_WEIGHT, std::to_string(miss) + " weights not loaded (first: " + first + ")");
+    }
+    return MTV_OK;
+}
+
+static int stage_inputs(mtv_ctx* c, const float* x, const float* cond, const float* image_cond, int ic_len, int B, hipStream_t s) {
+    const int L = c->lv[0].L, RR = c->lv[0].b1;
+    if (ic_len < RR) return fail(MTV_ERR_INVALID, "image_cond has fewer than R*R tokens");
+    if (x && x != c->xin) HIPCHK(hipMemcpyAsync(c->xin, x, (size_t)B * 4 * L * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->condin, cond, (size_t)B * 8 * L * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpy2DAsync(c->icin, (size_t)RR * 4, image_cond, (size_t)ic_len * 4, (size_t)RR * 4, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    return MTV_OK;
+}
+
+static int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_ops(c, p, c->cap_stream);
+    hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+    if (rc != MTV_OK) {
+        if (g) hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    return MTV_OK;
+}
+
+int mtv_forward(mtv_ctx* c, const float* x, const float* cond, const float* image_cond, int image_cond_len,
+                const int64_t* timesteps, float* eps_out, int batch, void* stream) {
+    int rc = check_ready(c, batch);
+    if (rc != MTV_OK) return rc;
+    if (!x || !cond || !image_cond || !timesteps || !eps_out) return fail(MTV_ERR_INVALID, "null tensor pointer");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    Plan* p = nullptr;
+    if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
+    if ((rc = stage_inputs(c, x, cond, image_cond, image_cond_len, batch, s)) != MTV_OK) return rc;
+    HIPCHK(hipMemcpyAsync(c->tbuf, timesteps, (size_t)batch * 8, hipMemcpyDeviceToDevice, s));
+    if (c->eager) {
+        if ((rc = run_ops(c, p, s)) != MTV_OK) return rc;
+    } else {
+        if (!p->g_forward && (rc = capture(c, p, &p->g_forward)) != MTV_OK) return rc;
+        HIPCHK(hipGraphLaunch(p->g_forward, s));
+    }
+    HIPCHK(hipMemcpyAsync(eps_out, c->eps, (size_t)batch * c->cfg.out_channels * c->lv[0].L * 4, hipMemcpyDeviceToDevice, s));
+    return MTV_OK;
+}
+
+int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* image_cond, int image_cond_len,
+                    const float* noise, int n_noise, const mtv_ddim_step* steps, int n_steps, int batch, void* stream) {
+    int rc = check_ready(c, batch);
+    if (rc != MTV_OK) return rc;
+    if (!x_io || !cond || !image_cond || !steps || n_steps < 1) return fail(MTV_ERR_INVALID, "null/empty argument");
+    if (c->cfg.out_channels != 4) return fail(MTV_ERR_INVALID, "DDIM loop needs out_channels == 4 (eps has the shape of x)");
+    for (int i = 0; i < n_steps; ++i) {
+        if (steps[i].noise_index >= n_noise) return fail(MTV_ERR_INVALID, "noise_index out of range");
+        if (steps[i].noise_index >= 0 && !noise) return fail(MTV_ERR_INVALID, "noise required");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    Plan* p = nullptr;
+    if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
+    // device-resident step table (grown geometrically; growing invalidates captured step graphs)
+    if (n_steps > c->d_steps_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (c->d_steps) hipFree(c->d_steps);
+        c->d_steps = nullptr;
+        int cap = 256;
+        while (cap < n_steps) cap *= 2;
+        HIPCHK(hipMalloc((void**)&c->d_steps, (size_t)cap * sizeof(DdimStep)));
+        c->d_steps_cap = cap;
+    }
+    static_assert(sizeof(DdimStep) == sizeof(mtv_ddim_step), "step layout");
+    // mark the end of the table so the advance kernel never reads t past n_steps
+    std::vector<DdimStep> host((const DdimStep*)steps, (const DdimStep*)steps + n_steps);
+    HIPCHK(hipMemcpyAsync(c->d_steps, host.data(), (size_t)n_steps * sizeof(DdimStep), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // `host` is pageable and dies at return
+    if ((rc = stage_inputs(c, x_io, cond, image_cond, image_cond_len, batch, s)) != MTV_OK) return rc;
+    HIPCHK(launch_ddim_init(c->d_steps, c->d_counter, c->tbuf, batch, s));
+    const int64_t n = (int64_t)batch * 4 * c->lv[0].L;
+    for (int i = 0; i < n_steps; ++i) {
+        // forward part: graph replay (or eager); tail: plain launches (noise pointer is a call argument)
+        if (c->eager) {
+            if ((rc = run_ops(c, p, s)) != MTV_OK) return rc;
+        } else {
+            if (!p->g_forward && (rc = capture(c, p, &p->g_forward)) != MTV_OK) return rc;
+            HIPCHK(hipGraphLaunch(p->g_forward, s));
+        }
+        HIPCHK(launch_ddim_update(c->xin, c->eps, noise, c->d_steps, c->d_counter, n, n, s));
+        HIPCHK(launch_ddim_advance(c->d_steps, c->d_counter, n_steps, c->tbuf, batch, s));
+    }
+    HIPCHK(hipMemcpyAsync(x_io, c->xin, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return MTV_OK;
+}
+
+int mtv_debug_tap(mtv_ctx* c, const char* name, float* dst, int64_t cap, int* tokens_out, int* channels_out) {
+    if (!c || !name) return fail(MTV_ERR_INVALID, "null argument");
+    auto it = c->taps.find(name);
+    if (it == c->taps.end()) return fail(MTV_ERR_INVALID, std::string("unknown tap: ") + name);
+    const int L = c->lv[it->second.first].L, C = it->second.second;
+    if (tokens_out) *tokens_out = L;
+    if (channels_out) *channels_out = C;
+    if (dst) {
+        int B = (int)(cap / ((int64_t)L * C));
+        if (B < 1) return fail(MTV_ERR_INVALID, "tap destination too small");
+        if (B > c->cfg.max_batch) B = c->cfg.max_batch;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(dst, c->bufs["tap." + std::string(name)], (size_t)B * L * C * 4, hipMemcpyDefault));
+    }
+    return MTV_OK;
+}
+
+int mtv_get_work(const mtv_ctx* c, mtv_work* out) {
+    if (!c || !out) return fail(MTV_ERR_INVALID, "null argument");
+    *out = c->work;
+    return MTV_OK;
+}
+
+int mtv_set_eager(mtv_ctx* c, int eager) {
+    if (!c) return fail(MTV_ERR_INVALID, "null context");
+    c->eager = eager != 0;
+    return MTV_OK;
+}
+
+}  // extern "C"
