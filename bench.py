@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- denoise-steps/sec of the MToV DDIM loop on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one B=1 UNet forward over a 16-frame 256x256 clip's tri-plane latent [1,4,2048]
++ the eta=1 DDIM update (BASELINE.json configs[1]: second-stage base UNet, 250 DDIM steps).
+Each rank denoises its own clip (clip-sharded, weak scaling); the only collective is the final
+all_gather of the 32 KiB latents, inside the timed region.  Weights are random-init including the
+reference's zero-initialised tensors, inputs/noise synthetic, already resident
+in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact f32 matrix peak
+
+
+def synth_weights_(module, device, seed):
+    """Random-init EVERY tensor (incl. zero_module'd convs and GN affine) on the device RNG:
+    >=2-D: U(-1,1)*sqrt(3/fan_in); GN gamma 1+0.2U; biases 0.2U (same recipe as filler.fill_tensor)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            if not torch.is_floating_point(v):
+                continue
+            u = torch.rand(v.shape, generator=g, device=device) * 2 - 1
+            if v.dim() >= 2:
+                fan_in = v[0].numel()
+                v.copy_(u * (3.0 / fan_in) ** 0.5)
+            elif k.endswith("weight"):
+                v.copy_(1.0 + 0.2 * u)
+            else:
+                v.copy_(0.2 * u)
+
+
+def cycled_steps(dm, K):
+    """K consecutive entries of the 250-step DDIM schedule (wrapping around if K > 250)."""
+    from moditalker_amd.ddpm import ddim_step_table
+    pairs = dm._time_pairs()
+    seq = [pairs[i % len(pairs)] for i in range(K)]
+    return ddim_step_table(dm.alphas_cumprod, dm.sqrt_recip_alphas_cumprod, dm.sqrt_recipm1_alphas_cumprod,
+                           seq, dm.ddim_sampling_eta)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="timed oracle steps for the cpu_baseline leg")
+    ap.add_argument("--profile-iters", type=int, default=5)
+    args = ap.parse_args()
+
+    import ctypes as C
+    import torch.distributed as dist
+    from moditalker_amd import BASE_UNET_CONFIG, DDPM, DiffusionWrapper, UNetModel, _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    R, T, S = 32, 16, 250
+    L = R * R + 2 * T * R
+    K, W = args.steps, args.warmup
+    net = DiffusionWrapper(UNetModel(**BASE_UNET_CONFIG, frames=T, max_batch=1)).eval().to(dev)
+    synth_weights_(net, dev, seed=1234)          # same weights on every rank (replica per GPU)
+    dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+    um = net.diffusion_model
+    g = torch.Generator(device=dev)
+    g.manual_seed(100 + rank)                    # each rank owns its clip and its noise stream
+    cond = torch.rand(1, 8, L, generator=g, device=dev) * 2 - 1
+    image_cond = torch.rand(1, 4, R * R, generator=g, device=dev) * 2 - 1
+    x = torch.randn(1, 4, L, generator=g, device=dev)
+    n_noise = max(K, W)
+    noise = torch.randn(n_noise, 1, 4, L, generator=g, device=dev)
+    ctx = um.hip_context(dev, 1)
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev)
+
+    def run(nsteps, xbuf):
+        steps, n_draws = cycled_steps(dm, nsteps)
+        _lib.check(lib.mtv_ddim_sample(ctx, xbuf.data_ptr(), cond.data_ptr(), image_cond.data_ptr(), R * R,
+                                       noise.data_ptr(), n_noise, steps, nsteps, 1, C.c_void_p(stream.cuda_stream)),
+                   "mtv_ddim_sample")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    xw = x.clone()
+    run(W, xw)                                    # warm-up: builds the plan, captures the graph
+    barrier()
+    xt = x.clone()
+    t0 = time.perf_counter()
+    run(K, xt)
+    if world > 1:                                 # final gather of the finished latents (32 KiB each)
+        out = [torch.empty_like(xt) for _ in range(world)]
+        dist.all_gather(out, xt)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert torch.isfinite(xt).all()
+
+    result = None
+    if rank == 0:
+        work = um.work(dev)
+        # ---- roofline of the dominant kernel family, measured live with hipEvents around every launch
+        prof = um.profile_forward(1, args.profile_iters, dev)
+        fam = {}
+        for p in prof:
+            key = p["name"].split(":")[0]
+            f = fam.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            f["ms"] += p["ms"]
+            f["flops"] += p["flops"]
+            f["bytes"] += p["bytes"]
+            f["launches"] += 1
+        conv = dict(ms=fam.get("conv3", {}).get("ms", 0) + fam.get("conv1", {}).get("ms", 0),
+                    flops=fam.get("conv3", {}).get("flops", 0) + fam.get("conv1", {}).get("flops", 0),
+                    bytes=fam.get("conv3", {}).get("bytes", 0) + fam.get("conv1", {}).get("bytes", 0),
+                    launches=fam.get("conv3", {}).get("launches", 0) + fam.get("conv1", {}).get("launches", 0))
+        attn = fam.get("attn", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        step_ms_events = sum(f["ms"] for f in fam.values())
+        dom_name, dom = ("k_conv", conv) if conv["ms"] >= attn["ms"] else ("k_attention", attn)
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TF,
+                        unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TF, 4), traffic=None,
+                        launches_per_step=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / max(1, dom["launches"]), 3),
+                        flops_per_step=dom["flops"],
+                        hbm_view=dict(algorithmic_bytes_per_step=dom["bytes"],
+                                      achieved_GBs=round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1) if dom["ms"] > 0 else 0.0,
+                                      peak_GBs=HBM_PEAK_GBS))
+        families = {k: dict(ms_per_step=round(v["ms"], 4), launches=v["launches"],
+                            tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] else None)
+                    for k, v in fam.items()}
+        # ---- CPU baseline: the oracle (PyTorch CPU restatement of the reference) on this box's cores
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ref_ddpm, ref_unet
+            ncores = max(1, (os.cpu_count() or 2) // 2)
+            torch.set_num_threads(ncores)
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items() if "output_bg_" not in k}
+            cfg = dict(BASE_UNET_CONFIG)
+            cc, ic, xc = cond.cpu(), image_cond.cpu(), x.cpu()
+            pairs = ref_ddpm.ddim_time_pairs(1000, S)
+            nz = noise[:, :, :, :].cpu()
+            buf = ref_ddpm.schedule_buffers()
+
+            def cpu_steps(n, img):
+                for i in range(n):
+                    time_, time_next = pairs[i]
+                    tt = torch.full((1,), time_, dtype=torch.long)
+                    eps = ref_unet.unet_forward(sd, cfg, img, cc, ic, tt, R, T)
+                    x0 = (buf["sqrt_recip_alphas_cumprod"][time_] * img - buf["sqrt_recipm1_alphas_cumprod"][time_] * eps).clamp_(-1, 1)
+                    a, an = buf["alphas_cumprod"][time_], buf["alphas_cumprod"][time_next]
+                    sigma = ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+                    c = (1 - an - sigma ** 2).sqrt()
+                    img = x0 * an.sqrt() + c * eps + sigma * nz[i]
+                return img
+
+            cpu_steps(1, xc)
+            tc = time.perf_counter()
+            cpu_steps(args.cpu_steps, xc)
+            tc = time.perf_counter() - tc
+            cpu = dict(value=round(args.cpu_steps / tc, 4), unit="denoise-steps/s", cores=ncores, kind="port",
+                       sample=f"first {args.cpu_steps} of the 250 DDIM steps of the same clip (after 1 warm-up step), "
+                              f"oracle/ref_unet.py op-for-op PyTorch {torch.__version__} CPU restatement, fp32")
+        result = {
+            "metric": "denoise-steps/sec (16-frame 256^2 clip, 250 DDIM steps)",
+            "value": round(world * K / dt, 3),
+            "unit": "denoise-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(1e3 * dt / K, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (random-init weights incl. zero-init tensors, U(-1,1) cond latents, N(0,1) noise)",
+            "config": {"workload": "configs[1]: 16-frame 256x256 clip = tri-plane latent [1,4,2048] (R=32,T=16), "
+                                   "base second-stage UNet (132.2M live params), DDIM eta=1, 250-step schedule, B=1 per GPU",
+                       "clips": world, "parallelism": f"clip-sharded x{world}, all_gather of latents at the end"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "step_ms_sum_of_launches": round(step_ms_events, 4),
+            "launches_per_step": work["n_launches"] + 2,
+            "flops_per_step": {k: work[k] for k in ("flops_conv3x3", "flops_1x1", "flops_attn_core", "flops_linear")},
+            "families": families,
+        }
+    barrier()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,17 @@ typedef struct mtv_work {
 } mtv_work;
 int mtv_get_work(const mtv_ctx* ctx, mtv_work* out);
 
+/* Per-launch timing of one UNet forward, measured with hipEvents on `stream` around every launch
+ * of the plan (plain launches, averaged over `iters` passes).  Call with out == NULL to get the
+ * number of launches in *n_out.  flops/bytes are the algorithmic figures of that launch. */
+typedef struct mtv_op_time {
+    char name[96];
+    float ms;
+    double flops;
+    double bytes;
+} mtv_op_time;
+int mtv_profile_forward(mtv_ctx* ctx, int batch, int iters, mtv_op_time* out, int cap, int* n_out, void* stream);
+
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
 int mtv_set_eager(mtv_ctx* ctx, int eager);
 

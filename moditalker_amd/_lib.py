@@ -64,6 +64,10 @@ class MtvWork(C.Structure):
     ]
 
 
+class MtvOpTime(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 # every symbol include/mtv_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
@@ -80,6 +84,7 @@ SYMBOLS = [
     ("mtv_debug_tap", C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("mtv_get_work", C.c_int, [_P, C.POINTER(MtvWork)]),
     ("mtv_set_eager", C.c_int, [_P, C.c_int]),
+    ("mtv_profile_forward", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(MtvOpTime), C.c_int, C.POINTER(C.c_int), _P]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -12,6 +12,8 @@
 // index of B/D may be permuted freely too.  Both freedoms are used so that every operand fragment
 // is a plain 16-byte global load: no LDS staging of operands is needed at the f32 MFMA rate.
 #include "mtv_internal.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace mtv {
 
@@ -52,8 +54,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     float* red = smem;
     if (a.gn.sums) {
         __shared__ float2 s_mr[3][32];
-        if (tid < 96) {
-            const int sg = tid >> 5, g = tid & 31;
+        for (int e = tid; e < 96; e += NW * 64) {
+            const int sg = e >> 5, g = e & 31;
             const double* S = a.gn.sums + (size_t)b * 192;
             double s, ss, n;
             if (a.gn.whole) {
@@ -236,6 +238,20 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks) {
     // Fill >= ~1024 waves (256 CUs x 4 SIMDs) while keeping the per-wave tile as large as the
     // problem allows (fewer L2 bytes per MFMA) and >= 2 chunks per wave.
     static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {1, 2}, {1, 1}};
+    // debugging / tuning aid: MTV_FORCE_TILE="MT,NT,NW" pins one tile shape for every conv
+    static int forced[3] = {-1, 0, 0};
+    if (forced[0] == -1) {
+        forced[0] = 0;
+        if (const char* e = getenv("MTV_FORCE_TILE")) {
+            int a = 0, b = 0, c = 0;
+            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { forced[0] = a; forced[1] = b; forced[2] = c; }
+        }
+    }
+    if (forced[0] > 0) {
+        ConvTile t{forced[0], forced[1], forced[2]};
+        if (t.NW > nchunks) t.NW = 1;
+        return t;
+    }
     ConvTile best{1, 1, 1};
     double best_score = -1.0;
     for (auto& c : cand) {
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const StatsArgs a) {
                 ss[e] += (double)v[e] * (double)v[e];
             }
         }
-        if (a.gs >= 4) {
+        if ((a.gs & 3) == 0) {   // the whole quad lies in one group
             const int g = c / a.gs;
             atomicAdd(&s_acc[g * 2], (s[0] + s[1]) + (s[2] + s[3]));
             atomicAdd(&s_acc[g * 2 + 1], (ss[0] + ss[1]) + (ss[2] + ss[3]));

@@ -75,6 +75,8 @@ struct Stage {
 struct Op {
     std::function<hipError_t(hipStream_t)> run;
     std::string name;
+    double flops = 0.0;    // algorithmic FLOPs of this launch (at the plan's batch size)
+    double bytes = 0.0;    // algorithmic HBM bytes: weights once + activations in/out once
 };
 
 struct Plan {
@@ -131,12 +133,15 @@ struct mtv_ctx {
         if (it != bufs.end()) return it->second;
         void* p = nullptr;
         if (dmalloc(&p, floats * sizeof(float)) != MTV_OK) return nullptr;
-        hipMemset(p, 0, floats * sizeof(float));
+        (void)hipMemset(p, 0, floats * sizeof(float));
         bufs[name] = (float*)p;
         return (float*)p;
     }
     float* act(const std::string& name, int lvl, int C) {   // [max_batch][L_lvl][C]
-        return buf("act." + name, (size_t)cfg.max_batch * lv[lvl].L * C);
+        float* p = buf("act." + name, (size_t)cfg.max_batch * lv[lvl].L * C);
+        taps[name] = {lvl, C};            // every activation is retrievable by name (mtv_debug_tap)
+        bufs["tap." + name] = p;
+        return p;
     }
     WSlot* slot(const std::string& key, std::vector<int64_t> shape, Role role, float* dst, int ld) {
         auto it = slot_index.find(key);
@@ -328,7 +333,14 @@ struct Builder {
 
     Builder(mtv_ctx* ctx, Plan* p, int batch) : c(ctx), plan(p), B(batch), f(ctx->cfg), emb(ctx->emb_dim), film_out(nullptr) {}
 
-    void push(const std::string& name, std::function<hipError_t(hipStream_t)> fn) { plan->ops.push_back(Op{std::move(fn), name}); }
+    void push(const std::string& name, std::function<hipError_t(hipStream_t)> fn, double flops = 0.0, double bytes = 0.0) {
+        Op op;
+        op.run = std::move(fn);
+        op.name = name;
+        op.flops = flops;
+        op.bytes = bytes;
+        plan->ops.push_back(std::move(op));
+    }
 
     // ---- weights ----
     // conv weight (3x3 or 1x1 / conv1d) repacked to [tap][Cin][ld]; `dst`/`ld` given when it shares a fused buffer
@@ -361,7 +373,13 @@ struct Builder {
         const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
         const ConvTile t = conv_pick_tile(B, a.Lout, a.N, nchunks);
         account_conv(a);
-        push("conv:" + name, [a, t](hipStream_t s) { return launch_conv(a, t, s); });
+        const double K = (double)a.ntaps * a.Cmain + a.Cskip;
+        const double flops = 2.0 * B * a.Lout * a.N * K;
+        const double bytes = 4.0 * (K * a.N + a.N) +
+                             4.0 * B * ((double)a.Lsrc * a.Cmain + (double)a.Lskip * a.Cskip + (double)a.Lout * a.N + (a.res ? (double)a.Lout * a.N : 0.0));
+        char tag[64];
+        snprintf(tag, sizeof tag, "[%dx%d k%d t%d,%d,%d]", a.Lout, a.N, (int)K, t.MT, t.NT, t.NW);
+        push(std::string(a.ntaps == 9 ? "conv3:" : "conv1:") + name + tag, [a, t](hipStream_t s) { return launch_conv(a, t, s); }, flops, bytes);
     }
 
     void add_stats(const std::vector<Tens>& parts, int lvl, double* site) {
@@ -549,7 +567,11 @@ struct Builder {
         for (int i = 0; i < t.nseg; ++i) t.tile_prefix[i + 1] = t.tile_prefix[i] + (t.seg_len[i] + 15) / 16;
         if (c->accounting)
             for (int i = 0; i < t.nseg; ++i) c->work.flops_attn_core += 4.0 * H * (double)t.seg_len[i] * t.seg_len[i] * d;
-        push("attn:" + nm, [t](hipStream_t s) { return launch_attention(t, s); });
+        double aflops = 0.0;
+        for (int i = 0; i < t.nseg; ++i) aflops += 4.0 * B * H * (double)t.seg_len[i] * t.seg_len[i] * d;
+        char tag[64];
+        snprintf(tag, sizeof tag, "[L%d d%d %s]", L.L, d, whole ? "1d" : "2d");
+        push("attn:" + nm + tag, [t](hipStream_t s) { return launch_attention(t, s); }, aflops, 4.0 * B * L.L * 4.0 * C);
 
         Tens out;
         out.lvl = lvl; out.C = C; out.p = c->act(nm + ".out", lvl, C);
@@ -794,14 +816,14 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
 
 int mtv_destroy(mtv_ctx* c) {
     if (!c) return MTV_OK;
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     for (auto& kv : c->plans) {
-        if (kv.second->g_forward) hipGraphExecDestroy(kv.second->g_forward);
+        if (kv.second->g_forward) (void)hipGraphExecDestroy(kv.second->g_forward);
     }
-    if (c->cap_stream) hipStreamDestroy(c->cap_stream);
-    for (void* p : c->allocs) hipFree(p);
-    if (c->staging) hipFree(c->staging);
-    if (c->d_steps) hipFree(c->d_steps);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->staging) (void)hipFree(c->staging);
+    if (c->d_steps) (void)hipFree(c->d_steps);
     delete c;
     return MTV_OK;
 }
@@ -854,7 +876,7 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
         HIPCHK(hipMemcpy(s.dst, data, n * sizeof(float), hipMemcpyDefault));
     } else {
         if (c->staging_floats < n) {
-            if (c->staging) hipFree(c->staging);
+            if (c->staging) (void)hipFree(c->staging);
             c->staging = nullptr;
             c->staging_floats = 0;
             HIPCHK(hipMalloc((void**)&c->staging, n * sizeof(float)));
@@ -898,12 +920,12 @@ static int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out) {
     int rc = run_ops(c, p, c->cap_stream);
     hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
     if (rc != MTV_OK) {
-        if (g) hipGraphDestroy(g);
+        if (g) (void)hipGraphDestroy(g);
         return rc;
     }
     if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
     return MTV_OK;
 }
@@ -946,7 +968,7 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
     // device-resident step table (grown geometrically; growing invalidates captured step graphs)
     if (n_steps > c->d_steps_cap) {
         HIPCHK(hipStreamSynchronize(s));
-        if (c->d_steps) hipFree(c->d_steps);
+        if (c->d_steps) (void)hipFree(c->d_steps);
         c->d_steps = nullptr;
         int cap = 256;
         while (cap < n_steps) cap *= 2;
@@ -973,6 +995,46 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
         HIPCHK(launch_ddim_advance(c->d_steps, c->d_counter, n_steps, c->tbuf, batch, s));
     }
     HIPCHK(hipMemcpyAsync(x_io, c->xin, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return MTV_OK;
+}
+
+int mtv_profile_forward(mtv_ctx* c, int batch, int iters, mtv_op_time* out, int cap, int* n_out, void* stream) {
+    int rc = check_ready(c, batch);
+    if (rc != MTV_OK) return rc;
+    if (iters < 1 || !n_out) return fail(MTV_ERR_INVALID, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    Plan* p = nullptr;
+    if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
+    const int n = (int)p->ops.size();
+    *n_out = n;
+    if (!out) return MTV_OK;
+    if (cap < n) return fail(MTV_ERR_INVALID, "profile table too small");
+    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    for (int it = 0; it < iters; ++it) {
+        for (int i = 0; i < n; ++i) {
+            HIPCHK(hipEventRecord(ev[2 * i], s));
+            hipError_t e = p->ops[i].run(s);
+            if (e != hipSuccess) return fail(MTV_ERR_HIP, "launch " + p->ops[i].name + ": " + hipGetErrorString(e));
+            HIPCHK(hipEventRecord(ev[2 * i + 1], s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < n; ++i) {
+        std::memset(&out[i], 0, sizeof(mtv_op_time));
+        std::strncpy(out[i].name, p->ops[i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].ms = (float)(acc[i] / iters);
+        out[i].flops = p->ops[i].flops;
+        out[i].bytes = p->ops[i].bytes;
+    }
     return MTV_OK;
 }
 

@@ -238,6 +238,20 @@ class UNetModel(nn.Module):
         _lib.check(_lib.load().mtv_get_work(ctx, C.byref(w)), "mtv_get_work")
         return {f: getattr(w, f) for f, _ in w._fields_}
 
+    def profile_forward(self, batch: int = 1, iters: int = 5, device=None):
+        """Per-launch hipEvent timings of one forward (plain launches): list of dicts
+        {name, ms, flops, bytes}.  Inputs are whatever the staging buffers currently hold."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        ctx = self.hip_context(dev, batch)
+        lib = _lib.load()
+        n = C.c_int()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.mtv_profile_forward(ctx, batch, iters, None, 0, C.byref(n), stream), "mtv_profile_forward")
+        table = (_lib.MtvOpTime * n.value)()
+        with torch.cuda.device(dev):
+            _lib.check(lib.mtv_profile_forward(ctx, batch, iters, table, n.value, C.byref(n), stream), "mtv_profile_forward")
+        return [dict(name=t.name.decode(), ms=float(t.ms), flops=float(t.flops), bytes=float(t.bytes)) for t in table]
+
     # ------------------------------------------------------------------ reference-shaped API
     @torch.no_grad()
     def forward(self, x, cond=None, image_cond=None, timesteps=None, context=None, y=None, **kwargs):

@@ -60,7 +60,7 @@ ModelFn = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor], tor
 def ddim_sample(model: ModelFn, cond: torch.Tensor, image_cond: torch.Tensor, noise: Sequence[torch.Tensor],
                 sampling_timesteps: int, total_timesteps: int = 1000, eta: float = 1.0,
                 noised_start: Optional[torch.Tensor] = None, ratio_: Optional[float] = None,
-                buffers: Optional[dict] = None) -> torch.Tensor:
+                buffers: Optional[dict] = None, trajectory: Optional[list] = None) -> torch.Tensor:
     """model(x, cond, image_cond, t[B] int64) -> eps.  noise[0] is x_T (or the q_sample noise when
     `noised_start` is given); noise[1+i] is the draw of the i-th non-final step."""
     buf = buffers or schedule_buffers(total_timesteps)
@@ -76,6 +76,8 @@ def ddim_sample(model: ModelFn, cond: torch.Tensor, image_cond: torch.Tensor, no
     k = 1
     out = None
     for time, time_next in pairs:
+        if trajectory is not None:
+            trajectory.append(img.clone())     # x_t fed to the model at this step
         t = torch.full((batch,), time, dtype=torch.long)
         eps = model(img, cond, image_cond, t)
         # ddpm.py:278-282, 346-351
@@ -89,6 +91,8 @@ def ddim_sample(model: ModelFn, cond: torch.Tensor, image_cond: torch.Tensor, no
         c = (1 - alpha_next - sigma ** 2).sqrt()
         img = x_start * alpha_next.sqrt() + c * eps + sigma * noise[k]      # ddpm.py:398
         k += 1
+    if trajectory is not None:
+        trajectory.append(out.clone())
     return out
 
 

@@ -134,7 +134,14 @@ def test_other_geometries_vs_oracle(R, T, cfg, B):
 
 
 def test_config1_cpu_plumbing_case_matches_oracle_sampler():
-    """BASELINE config 1: DDIM 50 steps, 4-frame 64x64 clip (R=8,T=4), 3-level UNet; oracle on CPU vs HIP."""
+    """BASELINE config 1: DDIM 50 steps, 4-frame 64x64 clip (R=8,T=4), 3-level UNet; oracle on CPU vs HIP.
+
+    With random weights this tiny geometry (GroupNorm over 2x2 / 1x2 planes at the deepest level) is
+    chaotic: the oracle against ITSELF with a different CPU thread count moves the 50-step result by
+    5e-2 (measured, /tmp probe recorded in DESIGN.md), so an end-to-end comparison only measures fp32
+    summation order.  Parity is therefore checked one step ahead along the oracle's trajectory: every
+    one of the 50 steps (UNet forward at that t + DDIM update with that step's noise) must reproduce
+    the oracle's next state to 2e-4."""
     from oracle import ref_ddpm, ref_unet
     R, T, S = 8, 4, 50
     cfg = dict(SHALLOW_CFG, image_size=R)
@@ -144,11 +151,22 @@ def test_config1_cpu_plumbing_case_matches_oracle_sampler():
     x, cond, ic = filler.synthetic_inputs(1, R, T, seed=9, tag="cfg1")
     noise = filler.noise_list(S, (1, 4, L), seed=9, tag="cfg1.noise")
     sd = {k: v.cpu() for k, v in net.state_dict().items()}
-    ref = ref_ddpm.ddim_sample(lambda a, b, c, d: ref_unet.unet_forward(sd, cfg, a, b, c, d, R, T), cond, ic, noise, S)
+    traj = []
+    ref = ref_ddpm.ddim_sample(lambda a, b, c, d: ref_unet.unet_forward(sd, cfg, a, b, c, d, R, T), cond, ic, noise, S,
+                               trajectory=traj)
+    assert len(traj) == S + 1
     dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+    pairs = dm._time_pairs()
+    worst = 0.0
+    for i in range(S):
+        nz = [noise[i + 1].to(dev)] if i + 1 < S else []
+        nxt = dm._run_ddim(traj[i].to(dev), cond.to(dev), ic.to(dev), pairs[i:i + 1], nz)
+        worst = max(worst, _maxabs(nxt, traj[i + 1]))
+    assert worst <= FWD_TOL, worst
+    # and the full 50-step run executes end to end, stays clamped and lands near the oracle's sample
     z = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=[n.to(dev) for n in noise])
-    assert z.shape == (1, 4, L)
-    assert _maxabs(z, ref) <= SAMPLE_TOL
+    assert z.shape == (1, 4, L) and float(z.abs().max()) <= 1.0
+    assert float((z.cpu() - ref).abs().mean()) <= 0.05
 
 
 def test_batch_elements_are_independent():
@@ -159,7 +177,10 @@ def test_batch_elements_are_independent():
     t = torch.tensor([10, 500, 900], device=dev)
     full = net(x.to(dev), cond.to(dev), ic.to(dev), t)
     one = net(x[1:2].to(dev), cond[1:2].to(dev), ic[1:2].to(dev), t[1:2])
-    assert _maxabs(full[1:2], one.cpu()) <= 1e-6
+    # different batch sizes may pick different split-K tilings -> fp32 summation-order noise only
+    assert _maxabs(full[1:2], one.cpu()) <= 2e-5
+    again = net(x[1:2].to(dev), cond[1:2].to(dev), ic[1:2].to(dev), t[1:2])
+    assert _maxabs(again, one.cpu()) == 0.0
 
 
 def test_image_cond_tail_is_ignored():

@@ -1,0 +1,130 @@
+"""Host-side logic of the product (no GPU): checkpoint key layout, schedule buffers, DDIM step table,
+the C-ABI library's exports, loud failures off-GPU, synthetic-data recipe."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import BASE_CFG, GOLDEN, NARROW_CFG, ROOT
+from moditalker_amd import DDPM, DiffusionWrapper, MtvError, UNetModel, _lib, filler
+from moditalker_amd.ddpm import ddim_step_table, ddim_time_pairs
+
+
+def test_state_dict_layout_matches_reference_manifest():
+    """804 keys, same names, order and shapes as the reference DiffusionWrapper.state_dict()."""
+    g = np.load(os.path.join(GOLDEN, "base.npz"))
+    with torch.device("meta"):
+        m = DiffusionWrapper(UNetModel(**BASE_CFG))
+    sd = m.state_dict()
+    assert len(sd) == 804
+    assert list(sd.keys()) == list(g["keys"])
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert sum(1 for k in sd if ".output_bg_" in k) == 246
+
+
+def test_zero_init_sites_match_reference():
+    """Fresh modules zero the same convs the reference's zero_module does (unet.py:159,242,289,974)."""
+    m = UNetModel(**NARROW_CFG)
+    sd = m.state_dict()
+    zero = [k for k, v in sd.items() if v.dim() >= 2 and not v.any()]
+    assert zero and all(re.search(r"(out_layers\.3|proj_out|^out\.2)\.weight$", k) for k in zero)
+
+
+def test_schedule_buffers_bit_equal_reference():
+    g = np.load(os.path.join(GOLDEN, "schedule.npz"))
+    dm = DDPM(torch.nn.Identity(), channels=4, image_size=32, sampling_timesteps=50, w=0.0)
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+              "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+        assert np.array_equal(getattr(dm, k).numpy(), g[k]), k
+    assert dm.is_ddim_sampling and dm.num_timesteps == 1000 and dm.ddim_sampling_eta == 1.0
+    for S in (4, 50, 100, 250):
+        times = g[f"times_S{S}"].tolist()
+        assert ddim_time_pairs(1000, S) == list(zip(times[:-1], times[1:]))
+    dm100 = DDPM(torch.nn.Identity(), sampling_timesteps=100)
+    pairs = dm100._time_pairs(0.25)                      # ddpm.py:430: S=100, ratio .25 -> 25 steps from t=249
+    assert len(pairs) == 25 and pairs[0][0] == 249 and pairs[-1] == (9, -1)
+
+
+def test_ddim_step_table_matches_reference_arithmetic():
+    from oracle import ref_ddpm
+    buf = ref_ddpm.schedule_buffers()
+    pairs = ddim_time_pairs(1000, 50)
+    steps, n = ddim_step_table(buf["alphas_cumprod"], buf["sqrt_recip_alphas_cumprod"], buf["sqrt_recipm1_alphas_cumprod"], pairs, 1.0)
+    assert n == 49 and len(steps) == 50
+    ac = buf["alphas_cumprod"]
+    for i, (t, tn) in enumerate(pairs):
+        s = steps[i]
+        assert s.t == t
+        assert s.sqrt_recip_ac == float(buf["sqrt_recip_alphas_cumprod"][t])
+        if tn < 0:
+            assert s.last == 1 and s.noise_index == -1 and i == 49
+            continue
+        a, an = ac[t], ac[tn]
+        sigma = 1.0 * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()      # ddpm.py:393
+        c = (1 - an - sigma ** 2).sqrt()                               # ddpm.py:394
+        assert (s.sigma, s.c, s.sqrt_ac_next) == (float(sigma), float(c), float(an.sqrt()))
+        assert s.noise_index == i and s.last == 0
+    assert ctypes.sizeof(_lib.MtvDdimStep) == 32
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """Every function include/mtv_hip.h declares is exported (no compute call: no GPU here)."""
+    hdr = open(os.path.join(ROOT, "include", "mtv_hip.h")).read()
+    declared = set(re.findall(r"\b(mtv_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"mtv_config", "mtv_ctx", "mtv_ddim_step", "mtv_work", "mtv_op_time"}
+    lib = _lib.load()
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.mtv_version() >= 1
+    assert ctypes.sizeof(_lib.MtvConfig) == 4 * (4 + 8 + 1 + 8 + 5)
+
+
+def test_no_cpu_fallback():
+    net = DiffusionWrapper(UNetModel(**NARROW_CFG)).eval()
+    x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=1, tag="cpu")
+    with pytest.raises(MtvError):
+        net(x, cond, ic, torch.tensor([5]))
+    dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=4, w=0.0)
+    with pytest.raises(MtvError):
+        dm.sample(batch_size=1, cond=cond, image_cond=ic)
+    with pytest.raises(TypeError):
+        DDPM(torch.nn.Identity(), sampling_timesteps=4).sample(batch_size=1, cond=cond, image_cond=ic)
+    with pytest.raises(NotImplementedError):
+        DDPM(net, sampling_timesteps=1000).sample(batch_size=1, cond=cond, image_cond=ic)   # ancestral loop not built
+    if not torch.cuda.is_available():
+        cfg = _lib.MtvConfig()
+        ctx = ctypes.c_void_p()
+        rc = _lib.load().mtv_create(ctypes.byref(cfg), ctypes.byref(ctx))
+        assert rc < 0 and _lib.load().mtv_last_error()
+
+
+def test_unsupported_options_raise():
+    for kw in (dict(use_spatial_transformer=True, context_dim=512), dict(resblock_updown=False), dict(use_fp16=True),
+               dict(num_classes=10), dict(dims=3)):
+        with pytest.raises(NotImplementedError):
+            UNetModel(**dict(NARROW_CFG, **kw))
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "moditalker_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f
+
+
+def test_filler_is_deterministic_and_well_scaled():
+    a = filler.fill_tensor("diffusion_model.x.weight", (64, 32, 3, 3), seed=5)
+    b = filler.fill_tensor("diffusion_model.x.weight", (64, 32, 3, 3), seed=5)
+    assert torch.equal(a, b)
+    assert not torch.equal(a, filler.fill_tensor("diffusion_model.y.weight", (64, 32, 3, 3), seed=5))
+    assert abs(float(a.std()) - (1.0 / (32 * 9)) ** 0.5) < 0.1 * (1.0 / (32 * 9)) ** 0.5
+    n = filler.normal("n", (200000,), seed=1)
+    assert abs(float(n.mean())) < 0.01 and abs(float(n.std()) - 1.0) < 0.01

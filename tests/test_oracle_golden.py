@@ -1,0 +1,82 @@
+"""The oracle (oracle/ref_unet.py, oracle/ref_ddpm.py) against the golden vectors the REFERENCE
+produced (tests/golden/*.npz, written by tests/golden/make_golden.py in the build container).
+This is the oracle's pin; it runs on CPU everywhere."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import BASE_CFG, GOLDEN, NARROW_CFG, SHALLOW_CFG
+from moditalker_amd import filler
+from oracle import ref_ddpm, ref_unet
+
+TOL = 2e-5   # same ATen ops as the reference: differences are thread-count reorder noise only
+
+
+def _sd(cfg, seed):
+    """Recipe-filled state_dict of the keys the forward reads (prefix diffusion_model. as in the wrapper)."""
+    from moditalker_amd import UNetModel
+    shapes = {}
+    with torch.device("meta"):
+        m = UNetModel(**cfg)
+    for k, v in m.state_dict().items():
+        shapes[k] = tuple(v.shape)
+    used = set(ref_unet.used_keys(cfg))
+    return {k: filler.fill_tensor("diffusion_model." + k, shapes[k], seed) for k in used}
+
+
+@pytest.mark.parametrize("tag,cfg,seed", [("narrow", NARROW_CFG, 11), ("shallow", SHALLOW_CFG, 12)])
+def test_small_models_forward_taps_and_sampling(tag, cfg, seed):
+    g = np.load(os.path.join(GOLDEN, f"{tag}.npz"))
+    sd = _sd(cfg, seed)
+    B = int(g["batch"])
+    x, cond, ic = filler.synthetic_inputs(B, 32, 16, seed=seed, tag=tag)
+    t = torch.from_numpy(g["t"])
+    taps = {}
+    eps = ref_unet.unet_forward(sd, cfg, x, cond, ic, t, 32, 16, taps=taps)
+    assert float((eps - torch.from_numpy(g["eps"])).abs().max()) <= TOL
+    for k in g.files:
+        if k.startswith("tap_"):
+            assert float((taps[k[4:]][..., ::7] - torch.from_numpy(g[k])).abs().max()) <= TOL, k
+    model = lambda a, b, c, d: ref_unet.unet_forward(sd, cfg, a, b, c, d, 32, 16)
+    for S, ratio in ((8, None), (20, 0.25)):
+        n = ref_ddpm.num_noise_draws(S, ratio)
+        noise = filler.noise_list(n, (B, 4, 2048), seed=seed, tag=f"{tag}.S{S}")
+        ns = filler.uniform_pm1(f"{tag}.noised_start", (B, 4, 2048), seed) if ratio else None
+        z = ref_ddpm.ddim_sample(model, cond, ic, noise, S, noised_start=ns, ratio_=ratio)
+        nm = f"sample_S{S}" + (f"_r{ratio}" if ratio else "")
+        assert float((z - torch.from_numpy(g[nm])).abs().max()) <= 1e-4, nm
+        # fix_noise only changes WHERE the first draw comes from (ddpm.py:424-427); with injected noise it is identical
+        if ratio:
+            assert np.array_equal(g[nm], g[nm + "_fix"])
+
+
+def test_base_forward():
+    g = np.load(os.path.join(GOLDEN, "base.npz"))
+    sd = _sd(BASE_CFG, 7)
+    x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+    eps = ref_unet.unet_forward(sd, BASE_CFG, x, cond, ic, torch.tensor([500]), 32, 16)
+    assert float((eps - torch.from_numpy(g["eps_t500"])).abs().max()) <= TOL
+
+
+def test_schedule_and_time_pairs():
+    g = np.load(os.path.join(GOLDEN, "schedule.npz"))
+    buf = ref_ddpm.schedule_buffers()
+    for k, v in buf.items():
+        assert np.array_equal(v.numpy(), g[k]), k
+    for S in (4, 50, 100, 250):
+        times = g[f"times_S{S}"].tolist()
+        assert ref_ddpm.ddim_time_pairs(1000, S) == list(zip(times[:-1], times[1:]))
+    # S=50: 999, 979, ..., 19, -1 ; S=250: 999, 995, ..., 3, -1  
+    assert g["times_S50"][:3].tolist() == [999, 979, 959] and g["times_S50"][-2:].tolist() == [19, -1]
+    assert g["times_S250"][:3].tolist() == [999, 995, 991] and g["times_S250"][-2:].tolist() == [3, -1]
+
+
+def test_block_structure_matches_survey_counts():
+    st = ref_unet.block_structure(BASE_CFG)
+    nres = sum(1 for s in st["inputs"] + [st["middle"]] + st["outputs"] for l in s if l[0] == "res")
+    nattn2 = sum(1 for s in st["inputs"] + [st["middle"]] + st["outputs"] for l in s if l[0] == "attn")
+    nattn1 = sum(1 for c in st["in_attn"] if c) + 1 + len(st["out_attn"])
+    assert (nres, nattn2, nattn1) == (28, 16, 24)
+    assert len(ref_unet.used_keys(BASE_CFG)) == 804 - 246  # 246 dead output_bg_* keys
