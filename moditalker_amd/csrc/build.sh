@@ -5,7 +5,8 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function"
 $HIPCC $FLAGS -c kernels.hip -o kernels.o "$@" &
+$HIPCC $FLAGS -c conv.hip -o conv.o "$@" &
 $HIPCC $FLAGS -c plan.hip -o plan.o "$@" &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC kernels.o plan.o -o libmtv_hip.so
+$HIPCC --offload-arch=gfx950 -shared -fPIC kernels.o conv.o plan.o -o libmtv_hip.so
 echo "built $(pwd)/libmtv_hip.so"

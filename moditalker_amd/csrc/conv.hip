@@ -1,0 +1,667 @@
+// Implicit-GEMM convolution for gfx950 on the exact-f32 matrix instruction v_mfma_f32_16x16x4_f32.
+//
+// Replaces: ResBlock in_layers / out_layers / skip_connection (MToV/models/ddpm/unet.py:131-167,
+// 178-207), the attention blocks' qkv / proj_out conv1d (unet.py:234,242,251,253), the stem and
+// head convs (unet.py:714,971-975), and the GroupNorm that precedes each of them
+// (diffusionmodules.py:156-173): normalisation + FiLM + SiLU are applied to the A operand on its
+// way to the matrix core, and the statistics of the OUTPUT are accumulated in the epilogue for the
+// GroupNorm sites that will consume it, so no separate normalisation pass ever touches HBM.
+//
+// MFMA 16x16x4 f32 operand maps (cdna_hip_programming.md section 3):
+//   A: lane l holds A[i = l&15][k = l>>4]     B: lane l holds B[k = l>>4][j = l&15]
+//   D: lane l, reg r holds D[row = 4*(l>>4) + r][col = l&15]
+// K is a reduction index, so A and B may use any common permutation of K, and the column index of
+// B/D may be permuted too.  Both freedoms are used so that every operand fragment is a plain
+// 16-byte global load (no LDS staging of operands is needed at the f32 MFMA rate):
+//   A: lane (i,q) loads x[row i][c0 + 4q .. 4q+3]; MFMA step s consumes component s, i.e. K slot q
+//      of step s is channel c0 + 4q + s;
+//   B: lane (j,q) loads W[c0 + 4q + s][n0 + NT*j .. +NT-1] for s = 0..3; column block nb of the
+//      wave tile is output channel n0 + NT*j + nb.
+//
+// Work split: grid.x = B * ceil(Lout / 16MT) row tiles (a tile never straddles a batch element),
+// grid.y = N / 16NT column tiles, grid.z = KS cross-workgroup K slices; the NW waves of a
+// workgroup split their K range further.  K = (tap, 16-channel chunk) pairs; each wave walks its
+// chunk range with a two-deep register pipeline (loads of chunk i+1 in flight under the MFMAs of
+// chunk i).  Waves are summed by a fixed-order LDS tree (deterministic); with KS > 1 the partial
+// tiles go to a slab and k_conv_finish adds them in fixed order.
+#include <cstdio>
+#include <cstdlib>
+
+#include "mtv_internal.h"
+
+namespace mtv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+__device__ __forceinline__ int seg_of(const SegInfo& s, int tok) { return tok >= s.b2 ? 2 : (tok >= s.b1 ? 1 : 0); }
+
+// K walk.  K is cut into SEGMENTS = (tap, source part) pairs -- the tapped parts for every tap, then
+// the parts of the fused 1x1 skip conv -- and each segment into chunks of 16 channels.  The segment
+// descriptors are built once per workgroup in LDS; a Cursor keeps the wave-uniform state in SGPRs
+// (forced with readfirstlane: the compiler cannot prove uniformity of anything derived from the wave
+// id) and the per-lane row offsets in VGPRs.  Advancing inside a segment is two scalar pointer bumps.
+#ifndef MTV_ABLATE
+#define MTV_ABLATE 0          // tools/ubench/conv_bench builds ablated variants: 1 no MFMA, 2 no A loads, 4 no B loads, 8 no transform
+#endif
+
+struct SegDesc {              // 32 bytes, one per segment, in LDS
+    unsigned src_lo, src_hi;  // base pointer of the source part
+    int Cp;                   // channels of the part
+    int Ls;                   // tokens per batch element of the source
+    int crow;                 // W row of channel 0 of this segment
+    int coff;                 // concat channel of channel 0 (coefficient index)
+    int tap;                  // row of the index table (== ntaps for skip segments)
+    int skip;
+};
+
+__device__ __forceinline__ int usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+typedef __attribute__((address_space(1))) const char gchar;   // global (not flat) loads: vmcnt only, saddr addressing
+
+template <int MT>
+struct Cursor {
+    int seg, c, cend, coff, skip;      // uniform
+    gchar* abase;                      // uniform: part base + c * 4
+    gchar* wbase;                      // uniform: W + (crow + c) * ldw * 4
+    unsigned rowoff[MT];               // per lane: ((b * Ls + st) * Cp + 4q) * 4
+    int e[MT];                         // per lane: index-table entries of this lane's rows for this tap
+};
+
+template <int MT>
+__device__ __forceinline__ void enter_segment(Cursor<MT>& k, const SegDesc* segs, const float* W, int ldw, const int* idx, int rows,
+                                              int b, int i, int q, int c) {
+    const SegDesc* d = segs + k.seg;
+    const unsigned lo = (unsigned)usgpr((int)d->src_lo), hi = (unsigned)usgpr((int)d->src_hi);
+    const int Cp = usgpr(d->Cp), Ls = usgpr(d->Ls), crow = usgpr(d->crow), tap = usgpr(d->tap);
+    k.coff = usgpr(d->coff);
+    k.skip = usgpr(d->skip);
+    k.c = c;
+    k.cend = Cp;
+    gchar* sp = (gchar*)(((unsigned long long)hi << 32) | lo);
+    k.abase = sp + (size_t)c * 4;
+    k.wbase = (gchar*)(unsigned long long)W + (size_t)(crow + c) * (size_t)ldw * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int e = idx[tap * rows + 16 * mt + i];
+        k.e[mt] = e;
+        const unsigned st = e < 0 ? 0u : (unsigned)(e & 0x0FFFFFFF);   // padded rows read a valid address, zeroed later
+        k.rowoff[mt] = (((unsigned)b * (unsigned)Ls + st) * (unsigned)Cp + 4u * q) * 4u;
+    }
+}
+
+template <int MT, int NT>
+struct Raw {
+    f32x4 a[MT];
+    int e[MT];
+    float b[4][NT];
+    int cc, skip;     // uniform: coefficient channel of this chunk, skip flag
+};
+
+template <int MT, int NT>
+__device__ __forceinline__ void load_chunk(const Cursor<MT>& k, unsigned woff, unsigned ldw4, Raw<MT, NT>& o) {
+    o.cc = k.coff + k.c;
+    o.skip = k.skip;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        gchar* p = k.wbase + (woff + (unsigned)s * ldw4);
+        if constexpr (MTV_ABLATE & 4) {
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) o.b[s][nb] = 0.5f;
+        } else if constexpr (NT == 4) {
+            const f32x4 t = *(const __attribute__((address_space(1))) f32x4*)p;
+            o.b[s][0] = t[0]; o.b[s][1] = t[1]; o.b[s][2] = t[2]; o.b[s][3] = t[3];
+        } else if constexpr (NT == 2) {
+            const f32x2 t = *(const __attribute__((address_space(1))) f32x2*)p;
+            o.b[s][0] = t[0]; o.b[s][1] = t[1];
+        } else {
+            o.b[s][0] = *(const __attribute__((address_space(1))) float*)p;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        o.e[mt] = k.e[mt];
+        if constexpr (MTV_ABLATE & 2) o.a[mt] = f32x4{1.f, 2.f, 3.f, 4.f};
+        else o.a[mt] = *(const __attribute__((address_space(1))) f32x4*)(k.abase + k.rowoff[mt]);
+    }
+}
+
+// coef holds, per (plane, channel), the folded affine {A, B}: y = x*A + B with A = gn_scale*(1+film_scale),
+// B = gn_bias*(1+film_scale) + film_shift  (GroupNorm affine and FiLM are both per-channel affine maps).
+template <int MT, int NT>
+__device__ __forceinline__ void mma_chunk(const float2* coef, int Cmain, bool do_gn, bool act, int q,
+                                          const Raw<MT, NT>& in, f32x4 (&acc)[MT][NT]) {
+    float av[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 v = in.a[mt];
+        const int e = in.e[mt];
+        if (do_gn && !in.skip && !(MTV_ABLATE & 8)) {
+            const int sg = e < 0 ? 0 : ((e >> 28) & 3);
+            const f32x4* cf = reinterpret_cast<const f32x4*>(coef + sg * Cmain + in.cc + 4 * q);
+            const f32x4 k0 = cf[0], k1 = cf[1];     // {A0,B0,A1,B1}, {A2,B2,A3,B3}
+            float y0 = fmaf(v[0], k0[0], k0[1]), y1 = fmaf(v[1], k0[2], k0[3]);
+            float y2 = fmaf(v[2], k1[0], k1[1]), y3 = fmaf(v[3], k1[2], k1[3]);
+            if (act) { y0 = silu_fast(y0); y1 = silu_fast(y1); y2 = silu_fast(y2); y3 = silu_fast(y3); }
+            v = f32x4{y0, y1, y2, y3};
+        }
+        if (e < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};              // conv zero padding applies AFTER norm/activation
+        av[mt][0] = v[0]; av[mt][1] = v[1]; av[mt][2] = v[2]; av[mt][3] = v[3];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                if constexpr (MTV_ABLATE & 1) acc[mt][nb][s] += av[mt][s] * in.b[s][nb];
+                else acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s], in.b[s][nb], acc[mt][nb], 0, 0, 0);
+            }
+}
+
+// bias / per-batch bias / residual epilogue of one output element
+__device__ __forceinline__ float epi(const ConvArgs& a, float v, int b, int tok, int rs, int nn) {
+    float o = v + a.bias[nn];
+    if (a.bias2) o += a.bias2[nn];
+    if (a.bias_b) o += a.bias_b[(size_t)b * a.bias_b_stride + nn];
+    if (a.res) o += a.res[((size_t)b * a.Lskip + rs) * a.N + nn];
+    return o;
+}
+
+__device__ __forceinline__ void stat_add(const ConvArgs& a, int b, int sg, int n, double s, double ss) {
+    for (int t = 0; t < a.nstat; ++t) {
+        const int g = (a.stat[t].coff + n) / a.stat[t].gs;
+        double* dst = a.stat[t].sums + (((size_t)b * 3 + sg) * 32 + g) * 2;
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, ss);
+    }
+}
+
+template <int MT, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float2 s_mr[3][32];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // SGPR: the K walk is scalar
+    const int i = lane & 15, q = lane >> 4;
+    constexpr int ROWS = 16 * MT, COLS = 16 * NT, NTH = NW * 64;
+    const int tiles_per_b = (a.Lout + ROWS - 1) / ROWS;
+    const int b = blockIdx.x / tiles_per_b;
+    const int tok0 = (blockIdx.x - b * tiles_per_b) * ROWS;
+    const int n0 = blockIdx.y * COLS;
+    const int Cmain = a.Cmain;
+    const bool do_gn = a.gn.sums != nullptr;
+
+    // ---- LDS: segment descriptors, source-token table [(ntaps+1)][ROWS], folded per-(plane, channel) affine {A, B}
+    constexpr int MAXSEG = 24;
+    SegDesc* segs = reinterpret_cast<SegDesc*>(smem);
+    int* idx = reinterpret_cast<int*>(smem + MAXSEG * 8);
+    const int idx_floats = ((a.ntaps + 1) * ROWS + 3) & ~3;
+    float2* coef = reinterpret_cast<float2*>(smem + MAXSEG * 8 + idx_floats);
+    const int nseg_main = a.ntaps * a.nmain, nseg = nseg_main + a.nskip;
+    if (tid < nseg) {
+        const bool skip = tid >= nseg_main;
+        const int local = skip ? tid - nseg_main : tid;
+        const int nparts = skip ? a.nskip : a.nmain;
+        const int tap = skip ? a.ntaps : (nparts > 1 ? local >> 1 : local);
+        const bool second = nparts > 1 && (local & 1);
+        const float* sp = skip ? (second ? a.src[3] : a.src[2]) : (second ? a.src[1] : a.src[0]);
+        SegDesc d;
+        d.src_lo = (unsigned)(reinterpret_cast<unsigned long long>(sp) & 0xFFFFFFFFull);
+        d.src_hi = (unsigned)(reinterpret_cast<unsigned long long>(sp) >> 32);
+        d.Cp = skip ? (second ? a.C[3] : a.C[2]) : (second ? a.C[1] : a.C[0]);
+        d.Ls = skip ? a.Lskip : a.Lsrc;
+        d.coff = second ? (skip ? a.C[2] : a.C[0]) : 0;
+        d.crow = (skip ? a.ntaps * Cmain : tap * Cmain) + d.coff;
+        d.tap = tap;
+        d.skip = skip ? 1 : 0;
+        segs[tid] = d;
+    }
+    for (int e = tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
+        const int t = e / ROWS, r = e - t * ROWS;
+        const int tok = tok0 + r;
+        int v = -1;
+        if (tok < a.Lout) {
+            if (t < a.ntaps) {
+                const int st = a.gather ? a.gather[t * a.Lout + tok] : tok;
+                v = st < 0 ? -1 : (st | (seg_of(a.seg_src, st) << 28));
+            } else {
+                v = a.gather_skip ? a.gather_skip[tok] : tok;
+            }
+        }
+        idx[e] = v;
+    }
+    if (do_gn) {
+        // per-channel inputs of the first round are requested BEFORE the statistics are reduced, so
+        // the two global-memory latencies overlap
+        constexpr int PER = 4;                          // channels per thread per round
+        float ga[PER], be[PER], s1[PER], sh[PER];
+        const float* film = a.gn.film ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
+        auto fetch = [&](int c0) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                ga[k] = a.gn.gamma[c0 + k];
+                be[k] = a.gn.beta[c0 + k];
+                s1[k] = film ? 1.0f + film[c0 + k] : 1.0f;
+                sh[k] = film ? film[Cmain + c0 + k] : 0.0f;
+            }
+        };
+        if (tid * PER < Cmain) fetch(tid * PER);
+        for (int e = tid; e < 96; e += NTH) {
+            const int sg = e >> 5, g = e & 31;
+            const double* S = a.gn.sums + (size_t)b * 192;
+            double s, ss, n;
+            if (a.gn.whole) {
+                s = S[g * 2] + S[64 + g * 2] + S[128 + g * 2];
+                ss = S[g * 2 + 1] + S[64 + g * 2 + 1] + S[128 + g * 2 + 1];
+                n = (double)a.seg_src.L * a.gn.gs;
+            } else {
+                s = S[sg * 64 + g * 2];
+                ss = S[sg * 64 + g * 2 + 1];
+                const int len = sg == 0 ? a.seg_src.b1 : (sg == 1 ? a.seg_src.b2 - a.seg_src.b1 : a.seg_src.L - a.seg_src.b2);
+                n = (double)len * a.gn.gs;
+            }
+            const double mean = s / n;
+            double var = ss / n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_mr[sg][g] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+        }
+        __syncthreads();
+        for (int c0 = tid * PER; c0 < Cmain; c0 += NTH * PER) {
+            if (c0 != tid * PER) fetch(c0);
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg)
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const float2 mr = s_mr[sg][(c0 + k) / a.gn.gs];
+                    const float sc = mr.y * ga[k];
+                    const float bi = be[k] - sc * mr.x;
+                    coef[sg * Cmain + c0 + k] = make_float2(sc * s1[k], fmaf(bi, s1[k], sh[k]));
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- K loop over this wave's chunk range, two-deep register pipeline
+    const int nchunks = a.ntaps * (Cmain >> 4) + (a.Cskip >> 4);
+    const int slice = blockIdx.z * NW + wave, nslices = a.KS * NW;
+    const int ch0 = usgpr((int)(((unsigned)nchunks * (unsigned)slice) / (unsigned)nslices));
+    const int ch1 = usgpr((int)(((unsigned)nchunks * (unsigned)(slice + 1)) / (unsigned)nslices));
+    const int ldw = a.ldw;
+    const float* Wp = a.W;
+    const unsigned ldw4 = (unsigned)ldw * 4u;
+    const unsigned woff = (4u * q * (unsigned)ldw + (unsigned)(n0 + NT * i)) * 4u;
+    const bool act = a.gn.act != 0;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (ch0 < ch1) {
+        Cursor<MT> cur;
+        {   // chunk index -> (segment, channel): walk the (few) segments once
+            int seg = 0, left = ch0;
+            while (seg + 1 < nseg) {
+                const int cp16 = usgpr(segs[seg].Cp) >> 4;
+                if (left < cp16) break;
+                left -= cp16;
+                ++seg;
+            }
+            cur.seg = seg;
+            enter_segment<MT>(cur, segs, Wp, ldw, idx, ROWS, b, i, q, left << 4);
+        }
+        auto advance = [&]() {
+            cur.c += 16;
+            if (cur.c < cur.cend) {
+                cur.abase += 64;
+                cur.wbase += (size_t)64 * (size_t)ldw;
+            } else {
+                cur.seg += 1;
+                enter_segment<MT>(cur, segs, Wp, ldw, idx, ROWS, b, i, q, 0);
+            }
+        };
+        Raw<MT, NT> r0, r1;
+        load_chunk<MT, NT>(cur, woff, ldw4, r0);
+        int n = ch1 - ch0;
+        // steady state: no conditionals, so r0 / r1 keep fixed registers and the loads of the next
+        // chunk stay in flight under the current chunk's MFMAs
+        while (n >= 3) {
+            advance();
+            load_chunk<MT, NT>(cur, woff, ldw4, r1);
+            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r0, acc);
+            advance();
+            load_chunk<MT, NT>(cur, woff, ldw4, r0);
+            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r1, acc);
+            n -= 2;
+        }
+        if (n == 2) {
+            advance();
+            load_chunk<MT, NT>(cur, woff, ldw4, r1);
+            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r0, acc);
+            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r1, acc);
+        } else {
+            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r0, acc);
+        }
+    }
+
+    // ---- fixed-order tree over the NW waves (lane-linear LDS image: conflict-free), LDS reused
+    __syncthreads();
+    float* red = smem;
+    constexpr int TILE_REGS = MT * NT * 4;
+#pragma unroll
+    for (int s = NW / 2; s >= 1; s >>= 1) {
+        if (wave >= s && wave < 2 * s) {
+            float* my = red + (size_t)(wave - s) * TILE_REGS * 64 + lane;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) my[((mt * NT + nb) * 4 + r) * 64] = acc[mt][nb][r];
+        }
+        __syncthreads();
+        if (wave < s) {
+            const float* my = red + (size_t)wave * TILE_REGS * 64 + lane;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][nb][r] += my[((mt * NT + nb) * 4 + r) * 64];
+        }
+        __syncthreads();
+    }
+    constexpr int LDR = COLS + 4;
+    if (wave == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) red[(16 * mt + 4 * q + r) * LDR + NT * i + nb] = acc[mt][nb][r];
+    }
+    __syncthreads();
+
+    // ---- pass 1 (row-major over the tile): epilogue + coalesced store
+    constexpr int QPR = COLS / 4, QUADS = ROWS * QPR;
+    const bool want_stats = a.nstat > 0 && a.KS == 1;
+    for (int e = tid; e < QUADS; e += NTH) {
+        const int rr = e / QPR, cq = e - rr * QPR;
+        const int tok = tok0 + rr, n = n0 + cq * 4;
+        if (tok >= a.Lout || n >= a.N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
+        if (a.KS > 1) {
+            float* dst = a.slab + (((size_t)blockIdx.z * a.B + b) * a.Lout + tok) * a.N + n;
+            if (n + 3 < a.N) *reinterpret_cast<f32x4*>(dst) = v;
+            else
+                for (int k = 0; k < 4 && n + k < a.N; ++k) dst[k] = v[k];
+            continue;
+        }
+        const int rs = (a.res && a.gather_skip) ? a.gather_skip[tok] : tok;   // (the LDS index table is gone by now)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (n + k < a.N) v[k] = epi(a, v[k], b, tok, rs, n + k);
+        if (!a.out_cm && n + 3 < a.N) {
+            *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
+        } else {
+            for (int k = 0; k < 4 && n + k < a.N; ++k) {
+                if (a.out_cm) a.out[((size_t)b * a.N + n + k) * a.Lout + tok] = v[k];
+                else a.out[((size_t)b * a.Lout + tok) * a.N + n + k] = v[k];
+            }
+        }
+        if (want_stats) *reinterpret_cast<f32x4*>(red + rr * LDR + cq * 4) = v;
+    }
+    if (!want_stats) return;
+
+    // ---- pass 2 (column-major over the tile): GroupNorm statistics of the output for its consumers
+    __syncthreads();
+    constexpr int W = ROWS < 64 ? ROWS : 64;         // lanes that share one channel quad
+    bool fast = true;
+    for (int t = 0; t < a.nstat; ++t) fast = fast && ((a.stat[t].gs & 3) == 0);
+    for (int base = 0; base < QUADS; base += NTH) {
+        const int e = base + tid;
+        const int cq = e / ROWS, rr = e - cq * ROWS;
+        const int tok = tok0 + rr, n = n0 + cq * 4;
+        const bool ok = e < QUADS && tok < a.Lout && n < a.N;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
+        const int sg = ok ? seg_of(a.seg_out, tok) : -1;
+        for (int sgi = 0; sgi < 3; ++sgi) {
+            if (!__any(sg == sgi)) continue;
+            const bool mine = sg == sgi;
+            if (fast) {
+                double s = mine ? ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]) : 0.0;
+                double ss = mine ? ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]) : 0.0;
+#pragma unroll
+                for (int o = W / 2; o >= 1; o >>= 1) {
+                    s += __shfl_xor(s, o);
+                    ss += __shfl_xor(ss, o);
+                }
+                if ((lane & (W - 1)) == 0 && e < QUADS && n < a.N) stat_add(a, b, sgi, n, s, ss);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double s = mine ? (double)v[k] : 0.0;
+                    double ss = mine ? (double)v[k] * v[k] : 0.0;
+#pragma unroll
+                    for (int o = W / 2; o >= 1; o >>= 1) {
+                        s += __shfl_xor(s, o);
+                        ss += __shfl_xor(ss, o);
+                    }
+                    if ((lane & (W - 1)) == 0 && e < QUADS && n + k < a.N) stat_add(a, b, sgi, n + k, s, ss);
+                }
+            }
+        }
+    }
+}
+
+// Completes a cross-workgroup split-K convolution: out = sum_ks slab[ks] (+ bias, residual), in fixed
+// order, plus the output's GroupNorm statistics.  grid (ceil(N/64), ceil(Lout/64), B), 256 threads:
+// thread = (row lane 0..15, channel quad 0..15) of a 64-token x 64-channel block.
+__global__ __launch_bounds__(256) void k_conv_finish(const ConvArgs a) {
+    __shared__ double s_st[3][64][2];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 3 * 64 * 2; e += 256) (&s_st[0][0][0])[e] = 0.0;
+    __syncthreads();
+    const int cq = tid & 15, rl = tid >> 4;
+    const int b = blockIdx.z;
+    const int n = blockIdx.x * 64 + cq * 4;
+    const int tok_lo = blockIdx.y * 64, tok_hi = min(a.Lout, tok_lo + 64);
+    double s[3][4], ss[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[g][k] = ss[g][k] = 0.0;
+    if (n < a.N) {
+        for (int tok = tok_lo + rl; tok < tok_hi; tok += 16) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < a.KS; ++ks) {
+                const float* src = a.slab + (((size_t)ks * a.B + b) * a.Lout + tok) * a.N + n;
+                if (n + 3 < a.N) v += *reinterpret_cast<const f32x4*>(src);
+                else
+                    for (int k = 0; k < 4 && n + k < a.N; ++k) v[k] += src[k];
+            }
+            const int rs = (a.res && a.gather_skip) ? a.gather_skip[tok] : tok;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (n + k < a.N) v[k] = epi(a, v[k], b, tok, rs, n + k);
+            if (!a.out_cm && n + 3 < a.N) {
+                *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
+            } else {
+                for (int k = 0; k < 4 && n + k < a.N; ++k) {
+                    if (a.out_cm) a.out[((size_t)b * a.N + n + k) * a.Lout + tok] = v[k];
+                    else a.out[((size_t)b * a.Lout + tok) * a.N + n + k] = v[k];
+                }
+            }
+            const int sg = seg_of(a.seg_out, tok);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                if (g == sg) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s[g][k] += (double)v[k];
+                        ss[g][k] += (double)v[k] * v[k];
+                    }
+                }
+        }
+    }
+    if (a.nstat == 0) return;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ss[g][k] != 0.0) {
+                atomicAdd(&s_st[g][cq * 4 + k][0], s[g][k]);
+                atomicAdd(&s_st[g][cq * 4 + k][1], ss[g][k]);
+            }
+    __syncthreads();
+    for (int e = tid; e < 3 * 64; e += 256) {
+        const int g = e >> 6, c = e & 63;
+        const int nn = blockIdx.x * 64 + c;
+        if (nn < a.N && s_st[g][c][1] != 0.0) stat_add(a, b, g, nn, s_st[g][c][0], s_st[g][c][1]);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// tile / split selection: a small analytic cost model (times in microseconds)
+// --------------------------------------------------------------------------------------------
+static size_t lds_bytes(int MT, int NT, int NW, int ntaps, int Cmain, bool has_gn) {
+    const int ROWS = 16 * MT, COLS = 16 * NT;
+    const size_t idx = (size_t)(((ntaps + 1) * ROWS + 3) & ~3) * 4 + 24 * 32;   // + segment descriptors
+    const size_t coef = has_gn ? (size_t)24 * Cmain : 0;
+    const size_t tree = (size_t)(NW / 2) * MT * NT * 4 * 64 * 4;
+    const size_t fin = (size_t)ROWS * (COLS + 4) * 4;
+    size_t r = idx + coef;
+    if (tree > r) r = tree;
+    if (fin > r) r = fin;
+    return r;
+}
+
+ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn) {
+    static int forced[4] = {-1, 0, 0, 0};   // tuning aid: MTV_FORCE_TILE="MT,NT,NW,KS"
+    if (forced[0] == -1) {
+        forced[0] = 0;
+        if (const char* e = getenv("MTV_FORCE_TILE")) {
+            int a = 0, b = 0, c = 0, d = 1;
+            if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3) { forced[0] = a; forced[1] = b; forced[2] = c; forced[3] = d < 1 ? 1 : d; }
+        }
+    }
+    if (forced[0] > 0) {
+        ConvTile t{forced[0], forced[1], forced[2], forced[3]};
+        while (t.NW * t.KS > nchunks && t.KS > 1) t.KS /= 2;
+        while (t.NW * t.KS > nchunks && t.NW > 1) t.NW /= 2;
+        return t;
+    }
+    static double lat_us = -1.0, fin_us = 2.5;
+    if (lat_us < 0) {
+        lat_us = 0.7;
+        if (const char* e = getenv("MTV_LAT_US")) lat_us = atof(e);
+        if (const char* e = getenv("MTV_FIN_US")) fin_us = atof(e);
+    }
+    static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
+    const int ntaps_guess = 9;
+    ConvTile best{1, 1, 1, 1};
+    double best_t = 1e30;
+    for (auto& c : cand) {
+        const int MT = c[0], NT = c[1];
+        if (NT > 1 && NT * 8 >= N) continue;                       // more than half of the tile's columns would be padding
+        if (MT > 1 && 16 * (MT / 2) >= Lout) continue;             // tile taller than needed
+        const double tiles = (double)B * ((Lout + 16 * MT - 1) / (16 * MT)) * ((N + 16 * NT - 1) / (16 * NT));
+        for (int NW = 1; NW <= 16; NW *= 2) {
+            if (lds_bytes(MT, NT, NW, ntaps_guess, Cmain, has_gn) > 96 * 1024) continue;
+            if (NW == 16 && MT * NT >= 8) continue;                   // 1024-thread blocks cap VGPRs at 128: these spill
+            for (int KS = 1; KS <= 16; KS *= 2) {
+                const int slices = NW * KS;
+                if (slices > nchunks) continue;
+                const double waves = tiles * slices;
+                const double cps = (double)nchunks / slices;
+                const double t_mfma = tiles * nchunks * (4.0 * MT * NT) * 32.0 / (waves < 1024 ? waves : 1024.0) / 2400.0;
+                const double t_lat = cps * lat_us;
+                const double t_l2 = tiles * nchunks * (MT + NT) * 1024.0 / 12e6;       // bytes / (12 TB/s) in us
+                double t = t_mfma > t_lat ? t_mfma : t_lat;
+                t = t > t_l2 ? t : t_l2;
+                t += 2.0 + 0.15 * (NW > 1 ? __builtin_ctz(NW) : 0);
+                if (KS > 1)   // slab round trip (write + KS-fold read) + the finish launch
+                    t += fin_us + (double)(KS + 1) * B * Lout * N * 4.0 / 3e6 + 0.1 * KS;
+                t += 0.002 * waves / 64;                                              // dispatch cost of very wide grids
+                if (t < best_t - 1e-9) {
+                    best_t = t;
+                    best = ConvTile{MT, NT, NW, KS};
+                }
+            }
+        }
+    }
+    return best;
+}
+
+size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
+    return lds_bytes(t.MT, t.NT, t.NW, a.ntaps, a.Cmain, a.gn.sums != nullptr);
+}
+
+template <int MT, int NT, int NW>
+static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t s) {
+    const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT);
+    dim3 grid(a.B * tiles, (a.N + 16 * NT - 1) / (16 * NT), a.KS);
+    const size_t smem = conv_smem_bytes(a, ConvTile{MT, NT, NW, a.KS});
+    hipLaunchKernelGGL((k_conv<MT, NT, NW>), grid, dim3(NW * 64), smem, s, a);
+    return hipGetLastError();
+}
+
+template <int MT, int NT>
+static hipError_t launch_conv_nw(const ConvArgs& a, int NW, hipStream_t s) {
+    switch (NW) {
+        case 1: return launch_conv_t<MT, NT, 1>(a, s);
+        case 2: return launch_conv_t<MT, NT, 2>(a, s);
+        case 4: return launch_conv_t<MT, NT, 4>(a, s);
+        case 8: return launch_conv_t<MT, NT, 8>(a, s);
+        case 16: return launch_conv_t<MT, NT, 16>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int MT, int NT, int NW>
+static hipError_t conv_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<MT, NT, NW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+}
+template <int MT, int NT>
+static hipError_t conv_attr_nw() {
+    hipError_t e;
+    if ((e = conv_attr<MT, NT, 1>()) != hipSuccess) return e;
+    if ((e = conv_attr<MT, NT, 2>()) != hipSuccess) return e;
+    if ((e = conv_attr<MT, NT, 4>()) != hipSuccess) return e;
+    if ((e = conv_attr<MT, NT, 8>()) != hipSuccess) return e;
+    return conv_attr<MT, NT, 16>();
+}
+// Dynamic LDS above 64 KB must be opted into once per kernel; done at mtv_create (never under capture).
+hipError_t conv_init_attrs() {
+    hipError_t e;
+    if ((e = conv_attr_nw<4, 4>()) != hipSuccess) return e;
+    if ((e = conv_attr_nw<2, 4>()) != hipSuccess) return e;
+    if ((e = conv_attr_nw<1, 4>()) != hipSuccess) return e;
+    if ((e = conv_attr_nw<2, 2>()) != hipSuccess) return e;
+    if ((e = conv_attr_nw<1, 2>()) != hipSuccess) return e;
+    return conv_attr_nw<1, 1>();
+}
+
+hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
+    ConvArgs a = a0;
+    a.KS = t.KS;
+    if (a.KS > 1 && !a.slab) return hipErrorInvalidValue;
+    hipError_t e = hipErrorInvalidValue;
+    if (t.MT == 4 && t.NT == 4) e = launch_conv_nw<4, 4>(a, t.NW, s);
+    else if (t.MT == 2 && t.NT == 4) e = launch_conv_nw<2, 4>(a, t.NW, s);
+    else if (t.MT == 1 && t.NT == 4) e = launch_conv_nw<1, 4>(a, t.NW, s);
+    else if (t.MT == 2 && t.NT == 2) e = launch_conv_nw<2, 2>(a, t.NW, s);
+    else if (t.MT == 1 && t.NT == 2) e = launch_conv_nw<1, 2>(a, t.NW, s);
+    else if (t.MT == 1 && t.NT == 1) e = launch_conv_nw<1, 1>(a, t.NW, s);
+    if (e != hipSuccess || a.KS == 1) return e;
+    hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 63) / 64, (a.Lout + 63) / 64, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace mtv

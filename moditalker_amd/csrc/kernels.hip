@@ -22,322 +22,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
 // =====================================================================================
-// Implicit-GEMM convolution (3x3 via gather table, 1x1, fused 1x1 skip), GN/FiLM/SiLU prologue
-// =====================================================================================
-// Replaces: ResBlock in_layers / out_layers / skip_connection (unet.py:131-167,178-207), the
-// attention blocks' qkv / proj_out conv1d (unet.py:234,242,251,253), the stem and head convs
-// (unet.py:714,971-975).
-//
-// Work split: grid.x = B * ceil(Lout / (16*MT)) row tiles (a tile never straddles a batch
-// element), grid.y = N / (16*NT) column tiles; the NW waves of a workgroup split the K axis
-// (taps x input channels, in chunks of 16 channels) and are summed in LDS in fixed order
-// (deterministic).  Per chunk a wave issues MT + 4 sixteen-byte loads for 16*MT*NT/4 MFMAs:
-//   A: lane (i,q) loads x[row i][c0 + 4q .. 4q+3]; MFMA step s uses component s, i.e. K slot q of
-//      step s is channel c0 + 4q + s;
-//   B: lane (j,q) loads W[c0 + 4q + s][n0 + NT*j .. +NT-1] for s = 0..3; column block nb of the
-//      wave tile is output channel n0 + NT*j + nb.
-template <int MT, int NT, int NW>
-__global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int i = lane & 15, q = lane >> 4;
-    constexpr int ROWS = 16 * MT, COLS = 16 * NT;
-    const int tiles_per_b = (a.Lout + ROWS - 1) / ROWS;
-    const int b = blockIdx.x / tiles_per_b;
-    const int tok0 = (blockIdx.x - b * tiles_per_b) * ROWS;
-    const int n0 = blockIdx.y * COLS;
-    const int Cmain = a.Cmain;
-
-    // ---- prologue: per-(plane, channel) affine coefficients {gn scale, gn bias, 1+film scale, film shift}
-    f32x4* coef = reinterpret_cast<f32x4*>(smem);
-    float* red = smem;
-    if (a.gn.sums) {
-        __shared__ float2 s_mr[3][32];
-        for (int e = tid; e < 96; e += NW * 64) {
-            const int sg = e >> 5, g = e & 31;
-            const double* S = a.gn.sums + (size_t)b * 192;
-            double s, ss, n;
-            if (a.gn.whole) {
-                s = S[g * 2] + S[64 + g * 2] + S[128 + g * 2];
-                ss = S[g * 2 + 1] + S[64 + g * 2 + 1] + S[128 + g * 2 + 1];
-                n = (double)a.seg_src.L * a.gn.gs;
-            } else {
-                s = S[sg * 64 + g * 2];
-                ss = S[sg * 64 + g * 2 + 1];
-                const int len = sg == 0 ? a.seg_src.b1 : (sg == 1 ? a.seg_src.b2 - a.seg_src.b1 : a.seg_src.L - a.seg_src.b2);
-                n = (double)len * a.gn.gs;
-            }
-            const double mean = s / n;
-            double var = ss / n - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            s_mr[sg][g] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
-        }
-        __syncthreads();
-        for (int idx = tid; idx < 3 * Cmain; idx += NW * 64) {
-            const int sg = idx / Cmain, c = idx - sg * Cmain;
-            const float2 mr = s_mr[sg][c / a.gn.gs];
-            const float sc = mr.y * a.gn.gamma[c];
-            const float bi = a.gn.beta[c] - sc * mr.x;
-            float s1 = 1.0f, sh = 0.0f;
-            if (a.gn.film) {
-                const float* f = a.gn.film + (size_t)b * a.gn.film_stride;
-                s1 = 1.0f + f[c];
-                sh = f[Cmain + c];
-            }
-            coef[idx] = f32x4{sc, bi, s1, sh};
-        }
-        red = smem + 12 * Cmain;
-        __syncthreads();
-    }
-
-    // ---- K loop over this wave's chunk range
-    const int cpm = Cmain >> 4;
-    const int nmain_chunks = a.ntaps * cpm;
-    const int nchunks = nmain_chunks + (a.Cskip >> 4);
-    const int ch0 = (int)(((long)nchunks * wave) / NW), ch1 = (int)(((long)nchunks * (wave + 1)) / NW);
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const bool do_gn = a.gn.sums != nullptr;
-    const int nbase = n0 + NT * i;   // this lane's first output column (i doubles as j for B)
-
-    for (int ch = ch0; ch < ch1; ++ch) {
-        const bool is_skip = ch >= nmain_chunks;
-        int tap = 0, c;
-        if (!is_skip) {
-            tap = ch / cpm;
-            c = (ch - tap * cpm) << 4;
-        } else {
-            c = (ch - nmain_chunks) << 4;
-        }
-        // which source part holds channel c
-        int p = is_skip ? a.nmain : 0;
-        int coff = 0;
-        const int pend = is_skip ? a.nmain + a.nskip : a.nmain;
-        while (p + 1 < pend && c >= coff + a.C[p]) {
-            coff += a.C[p];
-            ++p;
-        }
-        const float* sp = a.src[p];
-        const int Cp = a.C[p];
-        const int Ls = is_skip ? a.Lskip : a.Lsrc;
-        const int* gt = is_skip ? a.gather_skip : a.gather;
-
-        // B fragment: 4 rows of W, NT consecutive columns each
-        const size_t wrow = (size_t)(is_skip ? nmain_chunks * 16 + c : tap * Cmain + c) + 4 * q;
-        const float* wp = a.W + wrow * a.ldw + nbase;
-        float bv[4][NT];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if constexpr (NT == 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(wp + (size_t)s * a.ldw);
-                bv[s][0] = t[0]; bv[s][1] = t[1]; bv[s][2] = t[2]; bv[s][3] = t[3];
-            } else if constexpr (NT == 2) {
-                const float2 t = *reinterpret_cast<const float2*>(wp + (size_t)s * a.ldw);
-                bv[s][0] = t.x; bv[s][1] = t.y;
-            } else {
-                bv[s][0] = wp[(size_t)s * a.ldw];
-            }
-        }
-        // A fragment(s)
-        float av[MT][4];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int tok = tok0 + 16 * mt + i;
-            int st = -1;
-            if (tok < a.Lout) st = gt ? gt[(is_skip ? 0 : tap * a.Lout) + tok] : tok;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (st >= 0) {
-                v = *reinterpret_cast<const f32x4*>(sp + ((size_t)b * Ls + st) * Cp + (c - coff) + 4 * q);
-                if (do_gn && !is_skip) {
-                    const int sg = a.gn.whole ? 0 : (st >= a.seg_src.b2 ? 2 : (st >= a.seg_src.b1 ? 1 : 0));
-                    const f32x4* cf = coef + sg * Cmain + c + 4 * q;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x4 k = cf[e];
-                        float y = fmaf(v[e], k[0], k[1]);
-                        y = fmaf(y, k[2], k[3]);
-                        v[e] = a.gn.act ? silu_f(y) : y;
-                    }
-                }
-            }
-            av[mt][0] = v[0]; av[mt][1] = v[1]; av[mt][2] = v[2]; av[mt][3] = v[3];
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nb = 0; nb < NT; ++nb)
-                    acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s], bv[s][nb], acc[mt][nb], 0, 0, 0);
-    }
-
-    // ---- cross-wave (split-K) reduction in LDS, fixed order, then epilogue
-    constexpr int LDR = COLS + 4;
-    if (NW > 1) {
-        float* my = red + (size_t)wave * ROWS * LDR;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int nb = 0; nb < NT; ++nb) my[(16 * mt + 4 * q + r) * LDR + NT * i + nb] = acc[mt][nb][r];
-        __syncthreads();
-        constexpr int QUADS = ROWS * (COLS / 4);
-        for (int e = tid; e < QUADS; e += NW * 64) {
-            const int rr = e / (COLS / 4), cq = e - rr * (COLS / 4);
-            f32x4 v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
-#pragma unroll
-            for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(red + (size_t)w * ROWS * LDR + rr * LDR + cq * 4);
-            const int tok = tok0 + rr, n = n0 + cq * 4;
-            if (tok >= a.Lout || n >= a.N) continue;
-            int rs = tok;
-            if (a.res && a.gather_skip) rs = a.gather_skip[tok];
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const int nn = n + e4;
-                if (nn >= a.N) break;
-                float o = v[e4] + a.bias[nn];
-                if (a.bias2) o += a.bias2[nn];
-                if (a.bias_b) o += a.bias_b[(size_t)b * a.bias_b_stride + nn];
-                if (a.res) o += a.res[((size_t)b * a.Lskip + rs) * a.N + nn];
-                if (a.out_cm) a.out[((size_t)b * a.N + nn) * a.Lout + tok] = o;
-                else a.out[((size_t)b * a.Lout + tok) * a.N + nn] = o;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tok = tok0 + 16 * mt + 4 * q + r;
-                if (tok >= a.Lout) continue;
-                int rs = tok;
-                if (a.res && a.gather_skip) rs = a.gather_skip[tok];
-#pragma unroll
-                for (int nb = 0; nb < NT; ++nb) {
-                    const int nn = nbase + nb;
-                    if (nn >= a.N) break;
-                    float o = acc[mt][nb][r] + a.bias[nn];
-                    if (a.bias2) o += a.bias2[nn];
-                    if (a.bias_b) o += a.bias_b[(size_t)b * a.bias_b_stride + nn];
-                    if (a.res) o += a.res[((size_t)b * a.Lskip + rs) * a.N + nn];
-                    if (a.out_cm) a.out[((size_t)b * a.N + nn) * a.Lout + tok] = o;
-                    else a.out[((size_t)b * a.Lout + tok) * a.N + nn] = o;
-                }
-            }
-    }
-}
-
-ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks) {
-    // Fill >= ~1024 waves (256 CUs x 4 SIMDs) while keeping the per-wave tile as large as the
-    // problem allows (fewer L2 bytes per MFMA) and >= 2 chunks per wave.
-    static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {1, 2}, {1, 1}};
-    // debugging / tuning aid: MTV_FORCE_TILE="MT,NT,NW" pins one tile shape for every conv
-    static int forced[3] = {-1, 0, 0};
-    if (forced[0] == -1) {
-        forced[0] = 0;
-        if (const char* e = getenv("MTV_FORCE_TILE")) {
-            int a = 0, b = 0, c = 0;
-            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { forced[0] = a; forced[1] = b; forced[2] = c; }
-        }
-    }
-    if (forced[0] > 0) {
-        ConvTile t{forced[0], forced[1], forced[2]};
-        if (t.NW > nchunks) t.NW = 1;
-        return t;
-    }
-    ConvTile best{1, 1, 1};
-    double best_score = -1.0;
-    for (auto& c : cand) {
-        const int MT = c[0], NT = c[1];
-        if (NT * 16 > ((N + 15) / 16) * 16 && NT > 1) continue;     // tile wider than N
-        if (MT > 1 && 16 * (MT / 2) >= Lout) continue;               // tile taller than needed
-        const long tiles = (long)B * ((Lout + 16 * MT - 1) / (16 * MT)) * ((N + 16 * NT - 1) / (16 * NT));
-        for (int NW = 1; NW <= 16; NW *= 2) {
-            if (nchunks / NW < 1) break;
-            if ((size_t)NW * 16 * MT * (16 * NT + 4) * 4 > 64 * 1024) break;
-            const double waves = (double)tiles * NW;
-            const double fill = waves >= 1024.0 ? 1.0 : waves / 1024.0;
-            const double eff = (4.0 * MT * NT) / (MT + 4.0) / 8.0;   // MFMAs per load, normalised to (4,4)
-            const double chunks_per_wave = (double)nchunks / NW;
-            const double depth = chunks_per_wave >= 4 ? 1.0 : 0.6 + 0.1 * chunks_per_wave;
-            const double score = fill * (0.55 + 0.45 * eff) * depth;
-            if (score > best_score + 1e-9) {
-                best_score = score;
-                best = ConvTile{MT, NT, NW};
-            }
-        }
-    }
-    return best;
-}
-
-size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
-    size_t coef = a.gn.sums ? (size_t)12 * a.Cmain * sizeof(float) : 0;
-    size_t red = t.NW > 1 ? (size_t)t.NW * 16 * t.MT * (16 * t.NT + 4) * sizeof(float) : 0;
-    return coef + red;
-}
-
-template <int MT, int NT, int NW>
-static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t s) {
-    const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT);
-    dim3 grid(a.B * tiles, (a.N + 16 * NT - 1) / (16 * NT));
-    const size_t smem = conv_smem_bytes(a, ConvTile{MT, NT, NW});
-    hipLaunchKernelGGL((k_conv<MT, NT, NW>), grid, dim3(NW * 64), smem, s, a);
-    return hipGetLastError();
-}
-
-template <int MT, int NT>
-static hipError_t launch_conv_nw(const ConvArgs& a, int NW, hipStream_t s) {
-    switch (NW) {
-        case 1: return launch_conv_t<MT, NT, 1>(a, s);
-        case 2: return launch_conv_t<MT, NT, 2>(a, s);
-        case 4: return launch_conv_t<MT, NT, 4>(a, s);
-        case 8: return launch_conv_t<MT, NT, 8>(a, s);
-        case 16: return launch_conv_t<MT, NT, 16>(a, s);
-    }
-    return hipErrorInvalidValue;
-}
-
-template <int MT, int NT, int NW>
-static hipError_t conv_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv<MT, NT, NW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-}
-template <int MT, int NT>
-static hipError_t conv_attr_nw() {
-    hipError_t e;
-    if ((e = conv_attr<MT, NT, 1>()) != hipSuccess) return e;
-    if ((e = conv_attr<MT, NT, 2>()) != hipSuccess) return e;
-    if ((e = conv_attr<MT, NT, 4>()) != hipSuccess) return e;
-    if ((e = conv_attr<MT, NT, 8>()) != hipSuccess) return e;
-    return conv_attr<MT, NT, 16>();
-}
-// Dynamic LDS above 64 KB must be opted into once per kernel; done at mtv_create (never under capture).
-hipError_t conv_init_attrs() {
-    hipError_t e;
-    if ((e = conv_attr_nw<4, 4>()) != hipSuccess) return e;
-    if ((e = conv_attr_nw<2, 4>()) != hipSuccess) return e;
-    if ((e = conv_attr_nw<1, 4>()) != hipSuccess) return e;
-    if ((e = conv_attr_nw<1, 2>()) != hipSuccess) return e;
-    return conv_attr_nw<1, 1>();
-}
-
-hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s) {
-    if (t.MT == 4 && t.NT == 4) return launch_conv_nw<4, 4>(a, t.NW, s);
-    if (t.MT == 2 && t.NT == 4) return launch_conv_nw<2, 4>(a, t.NW, s);
-    if (t.MT == 1 && t.NT == 4) return launch_conv_nw<1, 4>(a, t.NW, s);
-    if (t.MT == 1 && t.NT == 2) return launch_conv_nw<1, 2>(a, t.NW, s);
-    if (t.MT == 1 && t.NT == 1) return launch_conv_nw<1, 1>(a, t.NW, s);
-    return hipErrorInvalidValue;
-}
-
-// =====================================================================================
 // GroupNorm statistics: fp64 (sum, sumsq) per (batch, plane, group)
 // =====================================================================================
 // Replaces the reduction half of GroupNorm32 (diffusionmodules.py:156-173).  Sources may be a
@@ -455,29 +139,46 @@ hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s) {
 // =====================================================================================
 // QKVAttentionLegacy core (unet.py:312-326), flash-style, exact-f32 MFMA, online softmax
 // =====================================================================================
-// One wave owns 16 queries of one (batch, segment, head) and walks the keys of its segment in
-// blocks of 64.  It computes S^T = K Q^T (keys x queries) so that a query is a lane COLUMN: the
-// softmax reductions over keys are 16 register values + two cross-lane steps, and the P^T
-// registers are directly the B operand of O^T += V^T P^T (K slot g of step s is key 4g+s, which
-// is exactly the D layout of S^T).  q and k are each pre-multiplied by d^-1/4 like the reference.
+// A workgroup = 4 waves = 64 consecutive queries of one (batch, segment, head); each wave owns 16
+// queries.  The keys of the segment are walked in blocks of KB (64, fewer for wide heads); the block's K rows and V^T (keys
+// contiguous) are staged in LDS once per workgroup, double buffered: the global loads of block j+1
+// are issued before block j is computed and written to the other buffer after it.
+// Per wave: S^T = K Q^T (keys x queries) so a query is a lane COLUMN -- the softmax reductions over
+// keys are 16 register values plus two cross-lane steps -- and the P^T registers are directly the
+// B operand of O^T += V^T P^T (K slot g of step s is key 4g+s, exactly the D layout of S^T).
+// q and k are each pre-multiplied by d^-1/4 like the reference.
 template <int D>
 __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
-    constexpr int VW = D >= 16 ? 4 : D / 4;        // floats per q/k vector load
-    constexpr int NV = D >= 16 ? D / 16 : 1;       // vector loads per row
+    constexpr int VW = D >= 16 ? 4 : D / 4;        // floats per q/k fragment
+    constexpr int NV = D >= 16 ? D / 16 : 1;       // fragments per row
     constexpr int NOB = D >= 16 ? D / 16 : 1;      // 16-row output blocks of O^T
-    constexpr int PVW = D >= 64 ? 4 : (D == 32 ? 2 : 1);   // V floats per load
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int KSTR = D + (D >= 32 ? 4 : 0);    // K row stride in LDS (floats)
+    constexpr int KB = D >= 128 ? 16 : (D >= 64 ? 32 : 64);   // keys per block (LDS budget)
+    constexpr int NKT = KB / 16;
+    constexpr int VSTR = KB + 4;                   // V^T row stride: KB keys + 4 (conflict-free b128 reads)
+    constexpr int VROWS = D < 16 ? 16 : D;
+    constexpr int QPR = D / 4;                     // float4 quads per K/V row
+    constexpr int NLD = (KB * QPR + 255) / 256;    // float4 loads per thread per tile
+    __shared__ __attribute__((aligned(16))) float Ks[2][KB * KSTR];
+    __shared__ __attribute__((aligned(16))) float Vt[2][VROWS * VSTR];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
-    const int qt = blockIdx.x * 4 + wave;
-    if (qt >= a.tile_prefix[a.nseg]) return;
+    // which (segment, 64-query block)
     int sg = 0;
-    while (sg + 1 < a.nseg && qt >= a.tile_prefix[sg + 1]) ++sg;
-    const int q0 = (qt - a.tile_prefix[sg]) * 16;
+    while (sg + 1 < a.nseg && (int)blockIdx.x >= a.blk_prefix[sg + 1]) ++sg;
+    const int q0 = (blockIdx.x - a.blk_prefix[sg]) * 64 + wave * 16;
     const int start = a.seg_start[sg], len = a.seg_len[sg];
     const int h = blockIdx.y, b = blockIdx.z;
     const int RS = 3 * a.C;
     const float* base = a.qkv + (size_t)b * a.L * RS + (size_t)h * 3 * D;
     const float scale = a.scale;
+
+    if (D < 16) {   // rows D..15 of V^T are never written: keep them zero (they feed masked MFMA rows)
+        for (int e = tid; e < 2 * VROWS * VSTR; e += 256) (&Vt[0][0])[e] = 0.f;
+        __syncthreads();
+    }
 
     float qreg[NV][VW];
     {
@@ -493,14 +194,46 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
     for (int o = 0; o < NOB; ++o) oacc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, lsum = 0.f;
 
-    for (int kb = 0; kb < len; kb += 64) {
-        f32x4 st[4];
+    // staging: thread -> (key, quad) of the 64 x D tile
+    f32x4 kreg[NLD], vreg[NLD];
+    auto gload = [&](int kb) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const int key = kb + kt * 16 + j;          // A operand row i = j
-            const bool ok = key < len;
-            const float* kp = base + (size_t)(start + (ok ? key : 0)) * RS + D + VW * g;
+        for (int r = 0; r < NLD; ++r) {
+            const int e = tid + 256 * r;
+            const int key = e / QPR, qd = e - key * QPR;
+            const bool ok = e < KB * QPR && kb + key < len;
+            const float* p = base + (size_t)(start + (ok ? kb + key : 0)) * RS + D + qd * 4;
+            kreg[r] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+            vreg[r] = ok ? *reinterpret_cast<const f32x4*>(p + D) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int e = tid + 256 * r;
+            const int key = e / QPR, qd = e - key * QPR;
+            if (e < KB * QPR) {
+                *reinterpret_cast<f32x4*>(&Ks[buf][key * KSTR + qd * 4]) = kreg[r] * scale;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Vt[buf][(qd * 4 + c) * VSTR + key] = vreg[r][c];
+            }
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kb = 0; kb < len; kb += KB) {
+        const bool more = kb + KB < len;
+        if (more) gload(kb + KB);                       // in flight under this block's math
+        const float* ks = Ks[buf];
+        const float* vt = Vt[buf];
+        f32x4 st[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
             f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* kp = ks + (kt * 16 + j) * KSTR + VW * g;
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 float kv[VW];
@@ -512,8 +245,7 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
                     for (int e = 0; e < VW; ++e) kv[e] = kp[e];
                 }
 #pragma unroll
-                for (int e = 0; e < VW; ++e)
-                    s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? kv[e] * scale : 0.f, qreg[u][e], s4, 0, 0, 0);
+                for (int e = 0; e < VW; ++e) s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[e], qreg[u][e], s4, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -522,7 +254,7 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
         }
         float mx = st[0][0];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -532,7 +264,7 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
         m = mn;
         float ps = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = __expf(st[kt][r] - mn);
@@ -542,68 +274,39 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
         lsum = lsum * alpha + ps;
 #pragma unroll
         for (int o = 0; o < NOB; ++o) oacc[o] *= alpha;
-        // O^T += V^T P^T
+        // O^T += V^T P^T : A = V^T rows (d index) x keys, read as 4 consecutive keys per lane
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            if (kb + kt * 16 >= len) break;
+        for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int key = kb + kt * 16 + 4 * g + s;
-                const bool ok = key < len;
-                const float* vp = base + (size_t)(start + (ok ? key : 0)) * RS + 2 * D;
-                const float p = st[kt][s];
-                if constexpr (D >= 64) {
+            for (int o = 0; o < NOB; ++o) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(vt + (16 * o + j) * VSTR + kt * 16 + 4 * g);
 #pragma unroll
-                    for (int u = 0; u < D / 64; ++u) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(vp + 64 * u + 4 * j);
-                        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb)
-                            oacc[4 * u + nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nb], p, oacc[4 * u + nb], 0, 0, 0);
-                    }
-                } else if constexpr (D == 32) {
-                    float2 v = *reinterpret_cast<const float2*>(vp + 2 * j);
-                    if (!ok) v = make_float2(0.f, 0.f);
-                    oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, p, oacc[0], 0, 0, 0);
-                    oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, p, oacc[1], 0, 0, 0);
-                } else {
-                    const float v = (ok && j < D) ? vp[j] : 0.f;
-                    oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, p, oacc[0], 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s) oacc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[s], st[kt][s], oacc[o], 0, 0, 0);
             }
         }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
     const float inv = 1.0f / lsum;
     if (q0 + j < len) {
         float* op = a.out + ((size_t)b * a.L + start + q0 + j) * a.C + (size_t)h * D;
-        if constexpr (D >= 64) {
+        if constexpr (D >= 16) {
 #pragma unroll
-            for (int u = 0; u < D / 64; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f32x4 o = f32x4{oacc[4 * u][r], oacc[4 * u + 1][r], oacc[4 * u + 2][r], oacc[4 * u + 3][r]};
-                    *reinterpret_cast<f32x4*>(op + 64 * u + 16 * g + 4 * r) = o * inv;
-                }
-        } else if constexpr (D == 32) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                op[8 * g + 2 * r] = oacc[0][r] * inv;
-                op[8 * g + 2 * r + 1] = oacc[1][r] * inv;
-            }
+            for (int o = 0; o < NOB; ++o) *reinterpret_cast<f32x4*>(op + 16 * o + 4 * g) = oacc[o] * inv;
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (4 * g + r < D) op[4 * g + r] = oacc[0][r] * inv;
         }
     }
-    (void)PVW;
 }
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     const int d = a.C / a.H;
-    dim3 grid((a.tile_prefix[a.nseg] + 3) / 4, a.H, a.B), block(256);
+    dim3 grid(a.blk_prefix[a.nseg], a.H, a.B), block(256);
     switch (d) {
         case 4: hipLaunchKernelGGL(k_attention<4>, grid, block, 0, s, a); break;
         case 8: hipLaunchKernelGGL(k_attention<8>, grid, block, 0, s, a); break;

@@ -25,9 +25,18 @@ struct GnIn {
     int act;              // 1: SiLU after the affine
 };
 
+// Producer-side GroupNorm statistics: a conv epilogue adds the (sum, sumsq) of its output to the
+// fp64 table of every GN site that will normalise this tensor (possibly as one part of a channel
+// concatenation: `coff` = offset of this tensor's channel 0 in the consumer's channel axis).
+struct StatOut {
+    double* sums;   // [B][3][32][2]
+    int gs;         // consumer's channels per group
+    int coff;
+};
+
 struct ConvArgs {
-    const float* src[4];  // parts [0,nmain): tapped sources (concatenated along channels);
-    int C[4];             //       [nmain, nmain+nskip): raw sources of the fused 1x1 skip conv
+    const float* src[4];  // [0..1]: tapped sources (<=2, concatenated along channels);
+    int C[4];             // [2..3]: raw sources of the fused 1x1 skip conv (<=2)
     int nmain, nskip;
     int Cmain, Cskip;
     const int* gather;       // [ntaps][Lout] source token per (tap, output token), -1 = zero pad; nullptr = identity
@@ -47,6 +56,11 @@ struct ConvArgs {
     const float* res;        // residual [B][Lskip][N] (identity skip) or nullptr
     float* out;
     int out_cm;              // 1: write channel-major [B][N][Lout] (the external layout)
+    SegInfo seg_out;         // plane boundaries of the output token axis (for the statistics)
+    StatOut stat[2];
+    int nstat;
+    int KS;                  // >1: cross-workgroup split-K; partial tiles go to `slab`, k_conv_finish completes
+    float* slab;             // [KS][B][Lout][N]
 };
 
 struct StatsArgs {
@@ -77,7 +91,7 @@ struct AttnArgs {
     int B, L, C, H;
     int nseg;
     int seg_start[3], seg_len[3];
-    int tile_prefix[4];      // prefix sums of ceil(seg_len/16)
+    int blk_prefix[4];       // prefix sums of ceil(seg_len/64): one workgroup per 64 queries
     float scale;             // d^-1/4, applied to q AND k (unet.py:322-323)
 };
 
@@ -97,10 +111,10 @@ struct DdimStep {            // mirror of mtv_ddim_step (include/mtv_hip.h)
 };
 
 // ---- launchers (kernels.hip) ----
-struct ConvTile { int MT, NT, NW; };
-ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks);
+struct ConvTile { int MT, NT, NW, KS; };
+ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn);
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t);
-hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s);
+hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s);   // + k_conv_finish when t.KS > 1
 hipError_t conv_init_attrs();
 hipError_t launch_gn_stats(const StatsArgs& a, hipStream_t s);
 hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s);

@@ -330,6 +330,8 @@ struct Builder {
     int emb;
     float* film_out;     // [maxB][film_total]
     std::string err;
+    std::map<const float*, std::shared_ptr<ConvArgs>> producer;   // tensor -> the conv that writes it
+    std::vector<std::pair<std::shared_ptr<ConvArgs>, ConvTile>> convs;
 
     Builder(mtv_ctx* ctx, Plan* p, int batch) : c(ctx), plan(p), B(batch), f(ctx->cfg), emb(ctx->emb_dim), film_out(nullptr) {}
 
@@ -368,21 +370,47 @@ struct Builder {
         }
     }
 
-    void add_conv(ConvArgs a, const std::string& name) {
-        a.B = B;
-        const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
-        const ConvTile t = conv_pick_tile(B, a.Lout, a.N, nchunks);
-        account_conv(a);
-        const double K = (double)a.ntaps * a.Cmain + a.Cskip;
-        const double flops = 2.0 * B * a.Lout * a.N * K;
-        const double bytes = 4.0 * (K * a.N + a.N) +
-                             4.0 * B * ((double)a.Lsrc * a.Cmain + (double)a.Lskip * a.Cskip + (double)a.Lout * a.N + (a.res ? (double)a.Lout * a.N : 0.0));
+    void add_conv(ConvArgs a0, const std::string& name, int lvl_out) {
+        a0.B = B;
+        a0.seg_out = c->lv[lvl_out].seg();
+        const int nchunks = a0.ntaps * (a0.Cmain / 16) + a0.Cskip / 16;
+        const ConvTile t = conv_pick_tile(B, a0.Lout, a0.N, nchunks, a0.Cmain, a0.gn.sums != nullptr);
+        account_conv(a0);
+        auto a = std::make_shared<ConvArgs>(a0);
+        producer[a->out] = a;
+        convs.push_back({a, t});
+        const double K = (double)a->ntaps * a->Cmain + a->Cskip;
+        const double flops = 2.0 * B * a->Lout * a->N * K;
+        const double bytes = 4.0 * (K * a->N + a->N) +
+                             4.0 * B * ((double)a->Lsrc * a->Cmain + (double)a->Lskip * a->Cskip + (double)a->Lout * a->N + (a->res ? (double)a->Lout * a->N : 0.0));
         char tag[64];
-        snprintf(tag, sizeof tag, "[%dx%d k%d t%d,%d,%d]", a.Lout, a.N, (int)K, t.MT, t.NT, t.NW);
-        push(std::string(a.ntaps == 9 ? "conv3:" : "conv1:") + name + tag, [a, t](hipStream_t s) { return launch_conv(a, t, s); }, flops, bytes);
+        snprintf(tag, sizeof tag, "[%dx%d k%d t%d,%d,%d,%d]", a->Lout, a->N, (int)K, t.MT, t.NT, t.NW, t.KS);
+        push(std::string(a->ntaps == 9 ? "conv3:" : "conv1:") + name + tag, [a, t](hipStream_t s) { return launch_conv(*a, t, s); }, flops, bytes);
     }
 
+    // GroupNorm site over the channel concatenation of `parts`: the statistics are accumulated by the
+    // epilogues of the convs that produce the parts; a standalone pass is only the fallback.
     void add_stats(const std::vector<Tens>& parts, int lvl, double* site) {
+        int ct = 0;
+        for (auto& p : parts) ct += p.C;
+        bool fused = true;
+        for (auto& p : parts) {
+            auto it = producer.find(p.p);
+            if (it == producer.end() || it->second->nstat >= 2 || it->second->out_cm) fused = false;
+        }
+        if (fused) {
+            int coff = 0;
+            for (auto& p : parts) {
+                ConvArgs& pa = *producer[p.p];
+                pa.stat[pa.nstat++] = StatOut{site, ct / 32, coff};
+                coff += p.C;
+            }
+            return;
+        }
+        add_stats_pass(parts, lvl, site);
+    }
+
+    void add_stats_pass(const std::vector<Tens>& parts, int lvl, double* site) {
         StatsArgs a{};
         a.nparts = (int)parts.size();
         int ct = 0;
@@ -480,7 +508,7 @@ struct Builder {
             a.seg_src = Li.seg();
             a.gn = GnIn{site1, g1, b1, nullptr, 0, cin / 32, 0, 1};
         }
-        add_conv(a, nm + ".conv1");
+        add_conv(a, nm + ".conv1", lvl_out);
 
         // GN2 statistics of h1
         double* site2 = c->new_site();
@@ -509,7 +537,7 @@ struct Builder {
         if (has_skip_conv) {
             if (r.updown) { err = "up/down block with skip conv"; return Tens{}; }
             d.nskip = (int)x.size();
-            for (int i = 0; i < d.nskip; ++i) { d.src[1 + i] = x[i].p; d.C[1 + i] = x[i].C; }
+            for (int i = 0; i < d.nskip; ++i) { d.src[2 + i] = x[i].p; d.C[2 + i] = x[i].C; }   // slots 2..3 = skip parts
             d.Cskip = cin;
             d.Lskip = Li.L;
             d.bias2 = sb;
@@ -519,7 +547,7 @@ struct Builder {
             else if (r.updown == 2) { d.res = x[0].p; d.Lskip = Li.L; d.gather_skip = c->gup1[lvl_out]; }
             else { d.res = x[0].p; d.Lskip = Lo.L; }
         }
-        add_conv(d, nm + ".conv2");
+        add_conv(d, nm + ".conv2", lvl_out);
         return out;
     }
 
@@ -549,7 +577,7 @@ struct Builder {
         a.ntaps = 1; a.Lout = L.L; a.Lsrc = L.L; a.N = 3 * C; a.W = Wq; a.ldw = ldq; a.bias = bq; a.out = qkv;
         a.nmain = 1; a.src[0] = x.p; a.C[0] = C; a.Cmain = C; a.seg_src = L.seg();
         a.gn = GnIn{site, gw, gb, nullptr, 0, C / 32, whole ? 1 : 0, 0};
-        add_conv(a, nm + ".qkv");
+        add_conv(a, nm + ".qkv", lvl);
 
         float* att = c->act(nm + ".att", lvl, C);
         AttnArgs t{};
@@ -563,8 +591,8 @@ struct Builder {
             t.seg_start[1] = L.b1; t.seg_len[1] = L.b2 - L.b1;
             t.seg_start[2] = L.b2; t.seg_len[2] = L.L - L.b2;
         }
-        t.tile_prefix[0] = 0;
-        for (int i = 0; i < t.nseg; ++i) t.tile_prefix[i + 1] = t.tile_prefix[i] + (t.seg_len[i] + 15) / 16;
+        t.blk_prefix[0] = 0;
+        for (int i = 0; i < t.nseg; ++i) t.blk_prefix[i + 1] = t.blk_prefix[i] + (t.seg_len[i] + 63) / 64;
         if (c->accounting)
             for (int i = 0; i < t.nseg; ++i) c->work.flops_attn_core += 4.0 * H * (double)t.seg_len[i] * t.seg_len[i] * d;
         double aflops = 0.0;
@@ -579,7 +607,7 @@ struct Builder {
         p.ntaps = 1; p.Lout = L.L; p.Lsrc = L.L; p.Lskip = L.L; p.N = C; p.W = Wp; p.ldw = ldp; p.bias = bp; p.out = out.p;
         p.nmain = 1; p.src[0] = att; p.C[0] = C; p.Cmain = C; p.seg_src = L.seg();
         p.res = x.p;
-        add_conv(p, nm + ".proj");
+        add_conv(p, nm + ".proj", lvl);
         return out;
     }
 
@@ -599,7 +627,7 @@ struct Builder {
                 ConvArgs a{};
                 a.ntaps = 9; a.Lout = L.L; a.Lsrc = L.L; a.N = ly.c; a.W = W; a.ldw = ld; a.bias = bias; a.out = cur.p;
                 a.nmain = 1; a.src[0] = x[0].p; a.C[0] = 16; a.Cmain = 16; a.gather = c->g3[0]; a.seg_src = L.seg();
-                add_conv(a, lnm);
+                add_conv(a, lnm, 0);
             } else if (ly.type == 1) {
                 cur = resblock(x, ly, lnm);
             } else {
@@ -688,9 +716,22 @@ struct Builder {
             a.out = c->eps; a.out_cm = 1;
             a.nmain = 1; a.src[0] = cur.p; a.C[0] = cur.C; a.Cmain = cur.C; a.gather = c->g3[0]; a.seg_src = L.seg();
             a.gn = GnIn{site, gw, gb, nullptr, 0, cur.C / 32, 0, 1};
-            add_conv(a, "head");
+            add_conv(a, "head", 0);
         }
         if (c->site_cursor > c->n_sites) return fail(MTV_ERR_INVALID, "GN site arena overflow");
+        {   // one slab shared by every cross-workgroup split-K conv of this plan (they run back to back)
+            size_t need = 0;
+            for (auto& cv : convs)
+                if (cv.second.KS > 1) {
+                    const size_t n = (size_t)cv.second.KS * B * cv.first->Lout * cv.first->N;
+                    need = n > need ? n : need;
+                }
+            if (need) {
+                float* slab = c->buf("slab.B" + std::to_string(B), need);
+                if (!slab) return fail(MTV_ERR_HIP, "slab allocation failed");
+                for (auto& cv : convs) cv.first->slab = slab;
+            }
+        }
         if (c->accounting) c->work.n_launches = (int)plan->ops.size();
         return MTV_OK;
     }
