@@ -1,3 +1,4 @@
-timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-python tools/profile_ops.py > gpurun_out/ops_r1_v5.txt 2>&1
-grep attn gpurun_out/ops_r1_v5.txt | sort -rn | awk 'NR%3==1' | head -16
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1b -o b -- python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_r1b_bench.json 2> $R/gpurun_out/prof_r1b.err
+ls $R/gpurun_out/prof_r1b | head

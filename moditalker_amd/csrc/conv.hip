@@ -44,7 +44,8 @@ __device__ __forceinline__ int seg_of(const SegInfo& s, int tok) { return tok >=
 // (forced with readfirstlane: the compiler cannot prove uniformity of anything derived from the wave
 // id) and the per-lane row offsets in VGPRs.  Advancing inside a segment is two scalar pointer bumps.
 #ifndef MTV_ABLATE
-#define MTV_ABLATE 0          // tools/ubench/conv_bench builds ablated variants: 1 no MFMA, 2 no A loads, 4 no B loads, 8 no transform
+#define MTV_ABLATE 0          // tools/ubench/conv_bench builds ablated variants: 1 no MFMA, 2 no A loads, 4 no B loads,
+                              // 8 no transform, 16 prologue only, 32 no reduction/epilogue
 #endif
 
 struct SegDesc {              // 32 bytes, one per segment, in LDS
@@ -59,6 +60,12 @@ struct SegDesc {              // 32 bytes, one per segment, in LDS
 
 __device__ __forceinline__ int usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+#if MTV_ABLATE & 64   // phase timestamps (shader clock) of thread 0 of four blocks -> a.dbg (conv_bench)
+#define MTV_STAMP(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y < 2 && blockIdx.z < 2) a.dbg[(blockIdx.y * 2 + blockIdx.z) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MTV_STAMP(k) do { } while (0)
+#endif
+
 typedef __attribute__((address_space(1))) const char gchar;   // global (not flat) loads: vmcnt only, saddr addressing
 
 template <int MT>
@@ -70,12 +77,12 @@ struct Cursor {
     int e[MT];                         // per lane: index-table entries of this lane's rows for this tap
 };
 
+// uniform half of entering a segment (needs only the segment table): everything the W loads need
 template <int MT>
-__device__ __forceinline__ void enter_segment(Cursor<MT>& k, const SegDesc* segs, const float* W, int ldw, const int* idx, int rows,
-                                              int b, int i, int q, int c) {
+__device__ __forceinline__ void enter_segment_u(Cursor<MT>& k, const SegDesc* segs, const float* W, int ldw, int c) {
     const SegDesc* d = segs + k.seg;
     const unsigned lo = (unsigned)usgpr((int)d->src_lo), hi = (unsigned)usgpr((int)d->src_hi);
-    const int Cp = usgpr(d->Cp), Ls = usgpr(d->Ls), crow = usgpr(d->crow), tap = usgpr(d->tap);
+    const int Cp = usgpr(d->Cp), crow = usgpr(d->crow);
     k.coff = usgpr(d->coff);
     k.skip = usgpr(d->skip);
     k.c = c;
@@ -83,6 +90,13 @@ __device__ __forceinline__ void enter_segment(Cursor<MT>& k, const SegDesc* segs
     gchar* sp = (gchar*)(((unsigned long long)hi << 32) | lo);
     k.abase = sp + (size_t)c * 4;
     k.wbase = (gchar*)(unsigned long long)W + (size_t)(crow + c) * (size_t)ldw * 4;
+}
+
+// per-lane half: byte offsets of this lane's A rows for the segment's tap (needs the index table)
+template <int MT>
+__device__ __forceinline__ void enter_segment_rows(Cursor<MT>& k, const SegDesc* segs, const int* idx, int rows, int b, int i, int q) {
+    const SegDesc* d = segs + k.seg;
+    const int Cp = usgpr(d->Cp), Ls = usgpr(d->Ls), tap = usgpr(d->tap);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int e = idx[tap * rows + 16 * mt + i];
@@ -101,7 +115,7 @@ struct Raw {
 };
 
 template <int MT, int NT>
-__device__ __forceinline__ void load_chunk(const Cursor<MT>& k, unsigned woff, unsigned ldw4, Raw<MT, NT>& o) {
+__device__ __forceinline__ void load_b(const Cursor<MT>& k, unsigned woff, unsigned ldw4, Raw<MT, NT>& o) {
     o.cc = k.coff + k.c;
     o.skip = k.skip;
 #pragma unroll
@@ -120,12 +134,22 @@ __device__ __forceinline__ void load_chunk(const Cursor<MT>& k, unsigned woff, u
             o.b[s][0] = *(const __attribute__((address_space(1))) float*)p;
         }
     }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void load_a(const Cursor<MT>& k, Raw<MT, NT>& o) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         o.e[mt] = k.e[mt];
         if constexpr (MTV_ABLATE & 2) o.a[mt] = f32x4{1.f, 2.f, 3.f, 4.f};
         else o.a[mt] = *(const __attribute__((address_space(1))) f32x4*)(k.abase + k.rowoff[mt]);
     }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void load_chunk(const Cursor<MT>& k, unsigned woff, unsigned ldw4, Raw<MT, NT>& o) {
+    load_b<MT, NT>(k, woff, ldw4, o);
+    load_a<MT, NT>(k, o);
 }
 
 // coef holds, per (plane, channel), the folded affine {A, B}: y = x*A + B with A = gn_scale*(1+film_scale),
@@ -194,6 +218,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     const int Cmain = a.Cmain;
     const bool do_gn = a.gn.sums != nullptr;
 
+    MTV_STAMP(0);
     // ---- LDS: segment descriptors, source-token table [(ntaps+1)][ROWS], folded per-(plane, channel) affine {A, B}
     constexpr int MAXSEG = 24;
     SegDesc* segs = reinterpret_cast<SegDesc*>(smem);
@@ -219,6 +244,36 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         d.skip = skip ? 1 : 0;
         segs[tid] = d;
     }
+    __syncthreads();
+
+    // ---- this wave's chunk range; the W fragment of its first chunk is requested NOW, so the (HBM-cold)
+    // weight latency overlaps the rest of the prologue
+    const int nchunks = a.ntaps * (Cmain >> 4) + (a.Cskip >> 4);
+    const int slice = blockIdx.z * NW + wave, nslices = a.KS * NW;
+    const int ch0 = usgpr((int)(((unsigned)nchunks * (unsigned)slice) / (unsigned)nslices));
+    const int ch1 = usgpr((int)(((unsigned)nchunks * (unsigned)(slice + 1)) / (unsigned)nslices));
+    const int ldw = a.ldw;
+    const float* Wp = a.W;
+    const unsigned ldw4 = (unsigned)ldw * 4u;
+    const unsigned woff = (4u * q * (unsigned)ldw + (unsigned)(n0 + NT * i)) * 4u;
+    // chunks in flight per wave, bounded by the register budget (1024-thread blocks get 128 VGPRs)
+    constexpr int DEPTH = NW == 16 ? (MT * NT >= 8 ? 2 : (MT * NT >= 4 ? 3 : 4)) : (MT * NT >= 16 ? 2 : (MT * NT >= 8 ? 3 : 4));
+    Cursor<MT> cur;
+    Raw<MT, NT> ring[DEPTH];
+    if (ch0 < ch1) {
+        int seg = 0, left = ch0;
+        while (seg + 1 < nseg) {
+            const int cp16 = usgpr(segs[seg].Cp) >> 4;
+            if (left < cp16) break;
+            left -= cp16;
+            ++seg;
+        }
+        cur.seg = seg;
+        enter_segment_u<MT>(cur, segs, Wp, ldw, left << 4);
+        load_b<MT, NT>(cur, woff, ldw4, ring[0]);
+    }
+
+    MTV_STAMP(1);
     for (int e = tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
         const int t = e / ROWS, r = e - t * ROWS;
         const int tok = tok0 + r;
@@ -266,7 +321,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             const double mean = s / n;
             double var = ss / n - mean * mean;
             var = var < 0.0 ? 0.0 : var;
-            s_mr[sg][g] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+            s_mr[sg][g] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));   // fp64 only where cancellation bites
         }
         __syncthreads();
         for (int c0 = tid * PER; c0 < Cmain; c0 += NTH * PER) {
@@ -284,15 +339,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     }
     __syncthreads();
 
+    if constexpr (MTV_ABLATE & 16) return;   // prologue only
+    MTV_STAMP(2);
     // ---- K loop over this wave's chunk range, two-deep register pipeline
-    const int nchunks = a.ntaps * (Cmain >> 4) + (a.Cskip >> 4);
-    const int slice = blockIdx.z * NW + wave, nslices = a.KS * NW;
-    const int ch0 = usgpr((int)(((unsigned)nchunks * (unsigned)slice) / (unsigned)nslices));
-    const int ch1 = usgpr((int)(((unsigned)nchunks * (unsigned)(slice + 1)) / (unsigned)nslices));
-    const int ldw = a.ldw;
-    const float* Wp = a.W;
-    const unsigned ldw4 = (unsigned)ldw * 4u;
-    const unsigned woff = (4u * q * (unsigned)ldw + (unsigned)(n0 + NT * i)) * 4u;
     const bool act = a.gn.act != 0;
 
     f32x4 acc[MT][NT];
@@ -302,18 +351,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (ch0 < ch1) {
-        Cursor<MT> cur;
-        {   // chunk index -> (segment, channel): walk the (few) segments once
-            int seg = 0, left = ch0;
-            while (seg + 1 < nseg) {
-                const int cp16 = usgpr(segs[seg].Cp) >> 4;
-                if (left < cp16) break;
-                left -= cp16;
-                ++seg;
-            }
-            cur.seg = seg;
-            enter_segment<MT>(cur, segs, Wp, ldw, idx, ROWS, b, i, q, left << 4);
-        }
+        enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q);
+        load_a<MT, NT>(cur, ring[0]);
         auto advance = [&]() {
             cur.c += 16;
             if (cur.c < cur.cend) {
@@ -321,79 +360,127 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
                 cur.wbase += (size_t)64 * (size_t)ldw;
             } else {
                 cur.seg += 1;
-                enter_segment<MT>(cur, segs, Wp, ldw, idx, ROWS, b, i, q, 0);
+                enter_segment_u<MT>(cur, segs, Wp, ldw, 0);
+                enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q);
             }
         };
-        Raw<MT, NT> r0, r1;
-        load_chunk<MT, NT>(cur, woff, ldw4, r0);
-        int n = ch1 - ch0;
-        // steady state: no conditionals, so r0 / r1 keep fixed registers and the loads of the next
-        // chunk stay in flight under the current chunk's MFMAs
-        while (n >= 3) {
-            advance();
-            load_chunk<MT, NT>(cur, woff, ldw4, r1);
-            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r0, acc);
-            advance();
-            load_chunk<MT, NT>(cur, woff, ldw4, r0);
-            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r1, acc);
-            n -= 2;
+        // ring of DEPTH chunks in flight.  Steady state has no conditionals, so every ring slot keeps
+        // fixed registers and the loads of the next DEPTH-1 chunks stay in flight under the MFMAs.
+        int n = ch1 - ch0;                       // chunks not yet multiplied (ring slot 0 holds the first)
+#pragma unroll
+        for (int d = 1; d < DEPTH; ++d)
+            if (d < n) {
+                advance();
+                load_chunk<MT, NT>(cur, woff, ldw4, ring[d]);
+            }
+        while (n >= 2 * DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, ring[d], acc);
+                advance();
+                load_chunk<MT, NT>(cur, woff, ldw4, ring[d]);
+            }
+            n -= DEPTH;
         }
-        if (n == 2) {
-            advance();
-            load_chunk<MT, NT>(cur, woff, ldw4, r1);
-            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r0, acc);
-            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r1, acc);
-        } else {
-            mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, r0, acc);
-        }
+        // drain: n < 2*DEPTH chunks left, min(n, DEPTH) of them already in the ring
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (d < n) {
+                mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, ring[d], acc);
+                if (d + DEPTH < n) {
+                    advance();
+                    load_chunk<MT, NT>(cur, woff, ldw4, ring[d]);
+                }
+            }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (d + DEPTH < n) mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, ring[d], acc);
     }
 
+    MTV_STAMP(3);
     // ---- fixed-order tree over the NW waves (lane-linear LDS image: conflict-free), LDS reused
     __syncthreads();
     float* red = smem;
     constexpr int TILE_REGS = MT * NT * 4;
-#pragma unroll
-    for (int s = NW / 2; s >= 1; s >>= 1) {
-        if (wave >= s && wave < 2 * s) {
-            float* my = red + (size_t)(wave - s) * TILE_REGS * 64 + lane;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nb = 0; nb < NT; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) my[((mt * NT + nb) * 4 + r) * 64] = acc[mt][nb][r];
-        }
-        __syncthreads();
-        if (wave < s) {
-            const float* my = red + (size_t)wave * TILE_REGS * 64 + lane;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nb = 0; nb < NT; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[mt][nb][r] += my[((mt * NT + nb) * 4 + r) * 64];
-        }
-        __syncthreads();
-    }
     constexpr int LDR = COLS + 4;
-    if (wave == 0) {
+    constexpr bool ONE_STAGE = NW > 1 && NW * TILE_REGS * 64 * 4 <= 48 * 1024;   // all partials fit in LDS at once
+    if constexpr (NW == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int nb = 0; nb < NT; ++nb) red[(16 * mt + 4 * q + r) * LDR + NT * i + nb] = acc[mt][nb][r];
+        __syncthreads();
+    } else if constexpr (ONE_STAGE) {
+        // every wave parks its partial tile (lane-linear image: conflict-free); pass 1 sums them in wave order
+        float* my = red + (size_t)wave * TILE_REGS * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) my[((mt * NT + nb) * 4 + r) * 64] = acc[mt][nb][r];
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int s = NW / 2; s >= 1; s >>= 1) {
+            if (wave >= s && wave < 2 * s) {
+                float* my = red + (size_t)(wave - s) * TILE_REGS * 64 + lane;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) my[((mt * NT + nb) * 4 + r) * 64] = acc[mt][nb][r];
+            }
+            __syncthreads();
+            if (wave < s) {
+                const float* my = red + (size_t)wave * TILE_REGS * 64 + lane;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[mt][nb][r] += my[((mt * NT + nb) * 4 + r) * 64];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) red[(16 * mt + 4 * q + r) * LDR + NT * i + nb] = acc[mt][nb][r];
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
+    MTV_STAMP(4);
     // ---- pass 1 (row-major over the tile): epilogue + coalesced store
     constexpr int QPR = COLS / 4, QUADS = ROWS * QPR;
     const bool want_stats = a.nstat > 0 && a.KS == 1;
+    float* fin = ONE_STAGE ? red + (size_t)NW * TILE_REGS * 64 : red;   // (row, col) image of the finished tile for pass 2
     for (int e = tid; e < QUADS; e += NTH) {
         const int rr = e / QPR, cq = e - rr * QPR;
         const int tok = tok0 + rr, n = n0 + cq * 4;
         if (tok >= a.Lout || n >= a.N) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
+        f32x4 v;
+        if constexpr (ONE_STAGE) {
+            // element (rr, 4cq+k) of wave w sits at w*TILE + ((mt*NT+nb)*4 + r)*64 + lane(i, q)
+            const int mt = rr >> 4, qq = (rr >> 2) & 3, r = rr & 3;
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int col = cq * 4 + k, ii = col / NT, nb = col - ii * NT;
+                    v[k] += red[(size_t)w * TILE_REGS * 64 + ((mt * NT + nb) * 4 + r) * 64 + qq * 16 + ii];
+                }
+        } else {
+            v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
+        }
         if (a.KS > 1) {
             float* dst = a.slab + (((size_t)blockIdx.z * a.B + b) * a.Lout + tok) * a.N + n;
             if (n + 3 < a.N) *reinterpret_cast<f32x4*>(dst) = v;
@@ -413,8 +500,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
                 else a.out[((size_t)b * a.Lout + tok) * a.N + n + k] = v[k];
             }
         }
-        if (want_stats) *reinterpret_cast<f32x4*>(red + rr * LDR + cq * 4) = v;
+        if (want_stats) *reinterpret_cast<f32x4*>(fin + rr * LDR + cq * 4) = v;
     }
+    MTV_STAMP(5);
     if (!want_stats) return;
 
     // ---- pass 2 (column-major over the tile): GroupNorm statistics of the output for its consumers
@@ -428,7 +516,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         const int tok = tok0 + rr, n = n0 + cq * 4;
         const bool ok = e < QUADS && tok < a.Lout && n < a.N;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
+        if (ok) v = *reinterpret_cast<const f32x4*>(fin + rr * LDR + cq * 4);
         const int sg = ok ? seg_of(a.seg_out, tok) : -1;
         for (int sgi = 0; sgi < 3; ++sgi) {
             if (!__any(sg == sgi)) continue;
@@ -465,6 +553,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
 __global__ __launch_bounds__(256) void k_conv_finish(const ConvArgs a) {
     __shared__ double s_st[3][64][2];
     const int tid = threadIdx.x;
+#if MTV_ABLATE & 64
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) a.dbg[6] = __builtin_amdgcn_s_memtime();
+#endif
     for (int e = tid; e < 3 * 64 * 2; e += 256) (&s_st[0][0][0])[e] = 0.0;
     __syncthreads();
     const int cq = tid & 15, rl = tid >> 4;
@@ -479,11 +570,22 @@ __global__ __launch_bounds__(256) void k_conv_finish(const ConvArgs a) {
     if (n < a.N) {
         for (int tok = tok_lo + rl; tok < tok_hi; tok += 16) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < a.KS; ++ks) {
-                const float* src = a.slab + (((size_t)ks * a.B + b) * a.Lout + tok) * a.N + n;
-                if (n + 3 < a.N) v += *reinterpret_cast<const f32x4*>(src);
-                else
-                    for (int k = 0; k < 4 && n + k < a.N; ++k) v[k] += src[k];
+            const size_t sstride = (size_t)a.B * a.Lout * a.N;
+            const float* src0 = a.slab + ((size_t)b * a.Lout + tok) * a.N + n;
+            if (n + 3 < a.N) {
+                // up to 16 slab loads in flight (the slabs were written by other CUs: each load is an
+                // L2/fabric round trip), then a fixed-order sum
+                for (int k0 = 0; k0 < a.KS; k0 += 16) {
+                    f32x4 t[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        t[k] = k0 + k < a.KS ? *reinterpret_cast<const f32x4*>(src0 + (size_t)(k0 + k) * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v += t[k];
+                }
+            } else {
+                for (int ks = 0; ks < a.KS; ++ks)
+                    for (int k = 0; k < 4 && n + k < a.N; ++k) v[k] += src0[(size_t)ks * sstride + k];
             }
             const int rs = (a.res && a.gather_skip) ? a.gather_skip[tok] : tok;
 #pragma unroll
@@ -509,6 +611,9 @@ __global__ __launch_bounds__(256) void k_conv_finish(const ConvArgs a) {
                 }
         }
     }
+#if MTV_ABLATE & 64
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) a.dbg[7] = __builtin_amdgcn_s_memtime();
+#endif
     if (a.nstat == 0) return;
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -533,11 +638,12 @@ static size_t lds_bytes(int MT, int NT, int NW, int ntaps, int Cmain, bool has_g
     const int ROWS = 16 * MT, COLS = 16 * NT;
     const size_t idx = (size_t)(((ntaps + 1) * ROWS + 3) & ~3) * 4 + 24 * 32;   // + segment descriptors
     const size_t coef = has_gn ? (size_t)24 * Cmain : 0;
-    const size_t tree = (size_t)(NW / 2) * MT * NT * 4 * 64 * 4;
+    const size_t part = (size_t)MT * NT * 4 * 64 * 4;                 // one wave's partial tile
     const size_t fin = (size_t)ROWS * (COLS + 4) * 4;
+    const bool one_stage = NW > 1 && NW * part <= 48 * 1024;
+    const size_t redu = one_stage ? NW * part + fin : ((size_t)(NW / 2) * part > fin ? (size_t)(NW / 2) * part : fin);
     size_t r = idx + coef;
-    if (tree > r) r = tree;
-    if (fin > r) r = fin;
+    if (redu > r) r = redu;
     return r;
 }
 

@@ -61,6 +61,7 @@ struct ConvArgs {
     int nstat;
     int KS;                  // >1: cross-workgroup split-K; partial tiles go to `slab`, k_conv_finish completes
     float* slab;             // [KS][B][Lout][N]
+    unsigned long long* dbg; // phase timestamps for tools/ubench/conv_bench (nullptr in the product)
 };
 
 struct StatsArgs {

@@ -7,6 +7,7 @@
 // ResBlocks in one GEMV, the whole step replayed as one hipGraph with a device-side step counter.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -79,8 +80,17 @@ struct Op {
     double bytes = 0.0;    // algorithmic HBM bytes: weights once + activations in/out once
 };
 
+struct ConvOp {                 // one convolution of the plan; args/tile are patched after creation
+    ConvArgs a;                 // (statistics targets, slab, auto-tuned tile), so launches read them late
+    ConvTile t;
+    std::string base_name;
+    int op_index = -1;
+};
+
 struct Plan {
     int B = 0;
+    std::vector<std::shared_ptr<ConvOp>> convs;
+    bool tuned = false;
     std::vector<Op> ops;           // UNet forward
     hipGraphExec_t g_forward = nullptr;
 };
@@ -120,6 +130,9 @@ struct mtv_ctx {
     bool accounting = false;
     float* staging = nullptr;
     size_t staging_floats = 0;
+    std::map<int, size_t> slab_floats;                    // per batch size
+    std::map<std::string, ConvTile> tune_cache;           // conv shape -> measured best tile
+    bool tune_cache_loaded = false;                       // MTV_TUNE_CACHE=<file>: persisted across processes
 
     // ---------------------------------------------------------------- memory helpers
     int dmalloc(void** p, size_t bytes) {
@@ -330,8 +343,7 @@ struct Builder {
     int emb;
     float* film_out;     // [maxB][film_total]
     std::string err;
-    std::map<const float*, std::shared_ptr<ConvArgs>> producer;   // tensor -> the conv that writes it
-    std::vector<std::pair<std::shared_ptr<ConvArgs>, ConvTile>> convs;
+    std::map<const float*, std::shared_ptr<ConvOp>> producer;   // tensor -> the conv that writes it
 
     Builder(mtv_ctx* ctx, Plan* p, int batch) : c(ctx), plan(p), B(batch), f(ctx->cfg), emb(ctx->emb_dim), film_out(nullptr) {}
 
@@ -370,22 +382,29 @@ struct Builder {
         }
     }
 
+    static std::string conv_tag(const ConvArgs& a, const ConvTile& t) {
+        char tag[80];
+        snprintf(tag, sizeof tag, "[%dx%d k%d t%d,%d,%d,%d]", a.Lout, a.N, a.ntaps * a.Cmain + a.Cskip, t.MT, t.NT, t.NW, t.KS);
+        return tag;
+    }
+
     void add_conv(ConvArgs a0, const std::string& name, int lvl_out) {
         a0.B = B;
         a0.seg_out = c->lv[lvl_out].seg();
         const int nchunks = a0.ntaps * (a0.Cmain / 16) + a0.Cskip / 16;
-        const ConvTile t = conv_pick_tile(B, a0.Lout, a0.N, nchunks, a0.Cmain, a0.gn.sums != nullptr);
         account_conv(a0);
-        auto a = std::make_shared<ConvArgs>(a0);
-        producer[a->out] = a;
-        convs.push_back({a, t});
-        const double K = (double)a->ntaps * a->Cmain + a->Cskip;
-        const double flops = 2.0 * B * a->Lout * a->N * K;
-        const double bytes = 4.0 * (K * a->N + a->N) +
-                             4.0 * B * ((double)a->Lsrc * a->Cmain + (double)a->Lskip * a->Cskip + (double)a->Lout * a->N + (a->res ? (double)a->Lout * a->N : 0.0));
-        char tag[64];
-        snprintf(tag, sizeof tag, "[%dx%d k%d t%d,%d,%d,%d]", a->Lout, a->N, (int)K, t.MT, t.NT, t.NW, t.KS);
-        push(std::string(a->ntaps == 9 ? "conv3:" : "conv1:") + name + tag, [a, t](hipStream_t s) { return launch_conv(*a, t, s); }, flops, bytes);
+        auto op = std::make_shared<ConvOp>();
+        op->a = a0;
+        op->t = conv_pick_tile(B, a0.Lout, a0.N, nchunks, a0.Cmain, a0.gn.sums != nullptr);
+        op->base_name = std::string(a0.ntaps == 9 ? "conv3:" : "conv1:") + name;
+        op->op_index = (int)plan->ops.size();
+        producer[a0.out] = op;
+        plan->convs.push_back(op);
+        const double K = (double)a0.ntaps * a0.Cmain + a0.Cskip;
+        const double flops = 2.0 * B * a0.Lout * a0.N * K;
+        const double bytes = 4.0 * (K * a0.N + a0.N) +
+                             4.0 * B * ((double)a0.Lsrc * a0.Cmain + (double)a0.Lskip * a0.Cskip + (double)a0.Lout * a0.N + (a0.res ? (double)a0.Lout * a0.N : 0.0));
+        push(op->base_name + conv_tag(op->a, op->t), [op](hipStream_t s) { return launch_conv(op->a, op->t, s); }, flops, bytes);
     }
 
     // GroupNorm site over the channel concatenation of `parts`: the statistics are accumulated by the
@@ -396,12 +415,12 @@ struct Builder {
         bool fused = true;
         for (auto& p : parts) {
             auto it = producer.find(p.p);
-            if (it == producer.end() || it->second->nstat >= 2 || it->second->out_cm) fused = false;
+            if (it == producer.end() || it->second->a.nstat >= 2 || it->second->a.out_cm) fused = false;
         }
         if (fused) {
             int coff = 0;
             for (auto& p : parts) {
-                ConvArgs& pa = *producer[p.p];
+                ConvArgs& pa = producer[p.p]->a;
                 pa.stat[pa.nstat++] = StatOut{site, ct / 32, coff};
                 coff += p.C;
             }
@@ -719,18 +738,20 @@ struct Builder {
             add_conv(a, "head", 0);
         }
         if (c->site_cursor > c->n_sites) return fail(MTV_ERR_INVALID, "GN site arena overflow");
-        {   // one slab shared by every cross-workgroup split-K conv of this plan (they run back to back)
+        {   // one slab shared by every cross-workgroup split-K conv of this plan (they run back to back);
+            // sized so the auto-tuner may try up to 16 K slices wherever that stays under 64 MB
             size_t need = 0;
-            for (auto& cv : convs)
-                if (cv.second.KS > 1) {
-                    const size_t n = (size_t)cv.second.KS * B * cv.first->Lout * cv.first->N;
-                    need = n > need ? n : need;
-                }
-            if (need) {
-                float* slab = c->buf("slab.B" + std::to_string(B), need);
-                if (!slab) return fail(MTV_ERR_HIP, "slab allocation failed");
-                for (auto& cv : convs) cv.first->slab = slab;
+            for (auto& op : plan->convs) {
+                const size_t one = (size_t)B * op->a.Lout * op->a.N;
+                size_t ks = 16;
+                while (ks > 1 && ks * one * 4 > ((size_t)64 << 20)) ks /= 2;
+                if ((size_t)op->t.KS > ks) ks = op->t.KS;
+                need = ks * one > need ? ks * one : need;
             }
+            float* slab = c->buf("slab.B" + std::to_string(B), need);
+            if (!slab) return fail(MTV_ERR_HIP, "slab allocation failed");
+            c->slab_floats[B] = need;
+            for (auto& op : plan->convs) op->a.slab = slab;
         }
         if (c->accounting) c->work.n_launches = (int)plan->ops.size();
         return MTV_OK;
@@ -738,6 +759,94 @@ struct Builder {
 };
 
 }  // namespace
+
+// Empirical tile selection: every distinct conv shape of the plan is timed once over the valid
+// (MT, NT, NW, KS) candidates with its real arguments (MTV_AUTOTUNE=0 keeps the analytic pick).
+static void tune_cache_load(mtv_ctx* c) {
+    const char* path = getenv("MTV_TUNE_CACHE");
+    if (!path || c->tune_cache_loaded) return;
+    c->tune_cache_loaded = true;
+    if (FILE* f = fopen(path, "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            char* bar = strchr(line, '|');
+            if (!bar) continue;
+            *bar = 0;
+            ConvTile t{};
+            if (sscanf(bar + 1, "%d %d %d %d", &t.MT, &t.NT, &t.NW, &t.KS) == 4) c->tune_cache[line] = t;
+        }
+        fclose(f);
+    }
+}
+
+static void tune_cache_append(const char* key, const ConvTile& t) {
+    const char* path = getenv("MTV_TUNE_CACHE");
+    if (!path) return;
+    if (FILE* f = fopen(path, "a")) {
+        fprintf(f, "%s|%d %d %d %d\n", key, t.MT, t.NT, t.NW, t.KS);
+        fclose(f);
+    }
+}
+
+static int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
+    if (p->tuned) return MTV_OK;
+    p->tuned = true;
+    tune_cache_load(c);
+    const char* env = getenv("MTV_AUTOTUNE");
+    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE")) return MTV_OK;
+    static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const size_t slab_cap = c->slab_floats[p->B];
+    for (auto& op : p->convs) {
+        const ConvArgs& a = op->a;
+        char key[160];
+        snprintf(key, sizeof key, "B%d L%d/%d/%d N%d t%d C%d+%d gn%d f%d r%d s%d cm%d", a.B, a.Lout, a.Lsrc, a.Lskip, a.N, a.ntaps, a.Cmain, a.Cskip,
+                 a.gn.sums ? 1 : 0, a.gn.film ? 1 : 0, a.res ? 1 : 0, a.nstat, a.out_cm);
+        auto it = c->tune_cache.find(key);
+        if (it == c->tune_cache.end()) {
+            const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
+            ConvTile best = op->t;
+            float best_ms = 1e30f;
+            for (auto& mn : cand) {
+                const int MT = mn[0], NT = mn[1];
+                if (NT > 1 && NT * 8 >= a.N) continue;
+                if (MT > 1 && 16 * (MT / 2) >= a.Lout) continue;
+                const long tiles = (long)a.B * ((a.Lout + 16 * MT - 1) / (16 * MT)) * ((a.N + 16 * NT - 1) / (16 * NT));
+                for (int NW = 1; NW <= 16; NW *= 2) {
+                    if (NW == 16 && MT * NT >= 8) continue;
+                    for (int KS = 1; KS <= 16; KS *= 2) {
+                        if (NW * KS > nchunks) continue;
+                        if (KS > 1 && (size_t)KS * a.B * a.Lout * a.N > slab_cap) continue;
+                        const long waves = tiles * NW * KS;
+                        if (waves > 16384 || (waves < 512 && tiles * KS < 64 && NW * KS * 2 <= nchunks && NW < 16)) continue;
+                        const ConvTile t{MT, NT, NW, KS};
+                        if (conv_smem_bytes(a, t) > 120 * 1024) continue;
+                        for (int w = 0; w < 2; ++w) HIPCHK(launch_conv(a, t, s));
+                        HIPCHK(hipEventRecord(e0, s));
+                        for (int w = 0; w < 6; ++w) HIPCHK(launch_conv(a, t, s));
+                        HIPCHK(hipEventRecord(e1, s));
+                        HIPCHK(hipEventSynchronize(e1));
+                        float ms = 0.f;
+                        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                        if (ms < best_ms) {
+                            best_ms = ms;
+                            best = t;
+                        }
+                    }
+                }
+            }
+            it = c->tune_cache.emplace(key, best).first;
+            tune_cache_append(key, best);
+        }
+        op->t = it->second;
+        p->ops[op->op_index].name = op->base_name + Builder::conv_tag(op->a, op->t);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return MTV_OK;
+}
 
 static int get_plan(mtv_ctx* c, int B, Plan** out) {
     auto it = c->plans.find(B);
@@ -980,6 +1089,7 @@ int mtv_forward(mtv_ctx* c, const float* x, const float* cond, const float* imag
     HIPCHK(hipSetDevice(c->device));
     Plan* p = nullptr;
     if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
+    if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
     if ((rc = stage_inputs(c, x, cond, image_cond, image_cond_len, batch, s)) != MTV_OK) return rc;
     HIPCHK(hipMemcpyAsync(c->tbuf, timesteps, (size_t)batch * 8, hipMemcpyDeviceToDevice, s));
     if (c->eager) {
@@ -1006,6 +1116,7 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
     HIPCHK(hipSetDevice(c->device));
     Plan* p = nullptr;
     if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
+    if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
     // device-resident step table (grown geometrically; growing invalidates captured step graphs)
     if (n_steps > c->d_steps_cap) {
         HIPCHK(hipStreamSynchronize(s));
@@ -1047,6 +1158,7 @@ int mtv_profile_forward(mtv_ctx* c, int batch, int iters, mtv_op_time* out, int 
     HIPCHK(hipSetDevice(c->device));
     Plan* p = nullptr;
     if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
+    if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
     const int n = (int)p->ops.size();
     *n_out = n;
     if (!out) return MTV_OK;

@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
     a.src[0] = x; a.C[0] = Cin; a.nmain = 1; a.Cmain = Cin; a.gather = ntaps == 9 ? dg : nullptr; a.ntaps = ntaps;
     a.Lout = L; a.Lsrc = L; a.Lskip = L; a.B = 1; a.W = W; a.ldw = ldw; a.N = N; a.bias = bias; a.out = out; a.seg_src = seg; a.seg_out = seg;
     a.slab = slab;
+    CK(hipMalloc(&a.dbg, 4096)); CK(hipMemset(a.dbg, 0, 4096));
     if (gn) a.gn = GnIn{sums, gamma, beta, nullptr, 0, Cin / 32, 0, 1};
     const double flops = 2.0 * L * N * (double)ntaps * Cin;
     const double wbytes = 4.0 * ntaps * Cin * N;
@@ -64,6 +65,19 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps;
         const int tiles = ((L + 16 * t.MT - 1) / (16 * t.MT)) * ((N + 16 * t.NT - 1) / (16 * t.NT));
+#if MTV_ABLATE & 64
+        {
+            unsigned long long st[32];
+            CK(hipMemcpy(st, a.dbg, sizeof st, hipMemcpyDeviceToHost));
+            for (int blk = 0; blk < 4; ++blk) {
+                printf("    blk(y%d,z%d) phases(clk): seg %5lld  prologue %5lld  kloop %6lld  wait+tree %6lld  epilogue %5lld | start+%lld", blk >> 1, blk & 1,
+                       (long long)(st[blk * 8 + 1] - st[blk * 8]), (long long)(st[blk * 8 + 2] - st[blk * 8 + 1]), (long long)(st[blk * 8 + 3] - st[blk * 8 + 2]),
+                       (long long)(st[blk * 8 + 4] - st[blk * 8 + 3]), (long long)(st[blk * 8 + 5] - st[blk * 8 + 4]), (long long)(st[blk * 8] - st[0]));
+                if (blk == 0 && t.KS > 1) printf("  finish: starts +%lld after main end, runs %lld", (long long)(st[6] - st[5]), (long long)(st[7] - st[6]));
+                printf("\n");
+            }
+        }
+#endif
         printf("  tile %d,%d,%d,%d  WGs %5d waves %6d : %8.2f us  %6.1f TF/s  %7.1f GB/s(w)\n", t.MT, t.NT, t.NW, t.KS, tiles * t.KS, tiles * t.KS * t.NW,
                us, flops / us / 1e6, wbytes / us / 1e3);
     };
