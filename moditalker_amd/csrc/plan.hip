@@ -1163,20 +1163,22 @@ int mtv_profile_forward(mtv_ctx* c, int batch, int iters, mtv_op_time* out, int 
     *n_out = n;
     if (!out) return MTV_OK;
     if (cap < n) return fail(MTV_ERR_INVALID, "profile table too small");
-    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    // one event between consecutive launches (n+1 in all): launch i is charged the interval between the
+    // event before it and the event after it, so the events' own cost is paid once per launch, not twice
+    std::vector<hipEvent_t> ev((size_t)n + 1);
     for (auto& e : ev) HIPCHK(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
     for (int it = 0; it < iters; ++it) {
+        HIPCHK(hipEventRecord(ev[0], s));
         for (int i = 0; i < n; ++i) {
-            HIPCHK(hipEventRecord(ev[2 * i], s));
             hipError_t e = p->ops[i].run(s);
             if (e != hipSuccess) return fail(MTV_ERR_HIP, "launch " + p->ops[i].name + ": " + hipGetErrorString(e));
-            HIPCHK(hipEventRecord(ev[2 * i + 1], s));
+            HIPCHK(hipEventRecord(ev[i + 1], s));
         }
         HIPCHK(hipStreamSynchronize(s));
         for (int i = 0; i < n; ++i) {
             float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             acc[i] += ms;
         }
     }
