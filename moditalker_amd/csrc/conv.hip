@@ -61,7 +61,7 @@ struct SegDesc {              // 32 bytes, one per segment, in LDS
 __device__ __forceinline__ int usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 #if MTV_ABLATE & 64   // phase timestamps (shader clock) of thread 0 of four blocks -> a.dbg (conv_bench)
-#define MTV_STAMP(k) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y < 2 && blockIdx.z < 2) a.dbg[(blockIdx.y * 2 + blockIdx.z) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MTV_STAMP(k) do { if (tid == 0 && blockIdx.x < 4) a.dbg[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MTV_STAMP(k) do { } while (0)
 #endif
@@ -212,9 +212,30 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     const int i = lane & 15, q = lane >> 4;
     constexpr int ROWS = 16 * MT, COLS = 16 * NT, NTH = NW * 64;
     const int tiles_per_b = (a.Lout + ROWS - 1) / ROWS;
-    const int b = blockIdx.x / tiles_per_b;
-    const int tok0 = (blockIdx.x - b * tiles_per_b) * ROWS;
-    const int n0 = blockIdx.y * COLS;
+    // block -> (row tile, column tile, K slice).  The dispatcher round-robins consecutive workgroups over
+    // the 8 XCDs (private L2s).  xmap 0: row tiles vary fastest (every L2 sees the whole -- small -- weight
+    // matrix).  xmap 1, for weight-dominated layers: workgroup id % 8 selects the (column tile, K slice)
+    // class, so each weight slice is fetched from HBM by exactly ONE L2 (speed only, never correctness).
+    const int tiles_n = (a.N + COLS - 1) / COLS;
+    const int Bt = a.B * tiles_per_b;
+    int bx, by, bz;
+    if (a.xmap == 0) {
+        bx = blockIdx.x % Bt;
+        const int rest = blockIdx.x / Bt;
+        by = rest % tiles_n;
+        bz = rest / tiles_n;
+    } else {
+        const int S = tiles_n * a.KS, Sx = (S + 7) >> 3;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int sl = xcd + 8 * (j % Sx);
+        if (sl >= S) return;                       // padding block (whole workgroup, before any barrier)
+        bx = j / Sx;
+        by = sl % tiles_n;
+        bz = sl / tiles_n;
+    }
+    const int b = bx / tiles_per_b;
+    const int tok0 = (bx - b * tiles_per_b) * ROWS;
+    const int n0 = by * COLS;
     const int Cmain = a.Cmain;
     const bool do_gn = a.gn.sums != nullptr;
 
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     // ---- this wave's chunk range; the W fragment of its first chunk is requested NOW, so the (HBM-cold)
     // weight latency overlaps the rest of the prologue
     const int nchunks = a.ntaps * (Cmain >> 4) + (a.Cskip >> 4);
-    const int slice = blockIdx.z * NW + wave, nslices = a.KS * NW;
+    const int slice = bz * NW + wave, nslices = a.KS * NW;
     const int ch0 = usgpr((int)(((unsigned)nchunks * (unsigned)slice) / (unsigned)nslices));
     const int ch1 = usgpr((int)(((unsigned)nchunks * (unsigned)(slice + 1)) / (unsigned)nslices));
     const int ldw = a.ldw;
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
         }
         if (a.KS > 1) {
-            float* dst = a.slab + (((size_t)blockIdx.z * a.B + b) * a.Lout + tok) * a.N + n;
+            float* dst = a.slab + (((size_t)bz * a.B + b) * a.Lout + tok) * a.N + n;
             if (n + 3 < a.N) *reinterpret_cast<f32x4*>(dst) = v;
             else
                 for (int k = 0; k < 4 && n + k < a.N; ++k) dst[k] = v[k];
@@ -548,8 +569,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
 }
 
 // Completes a cross-workgroup split-K convolution: out = sum_ks slab[ks] (+ bias, residual), in fixed
-// order, plus the output's GroupNorm statistics.  grid (ceil(N/64), ceil(Lout/64), B), 256 threads:
-// thread = (row lane 0..15, channel quad 0..15) of a 64-token x 64-channel block.
+// order, plus the output's GroupNorm statistics.  grid (ceil(N/64), ceil(Lout/16), B), 256 threads:
+// thread = (row lane 0..15, channel quad 0..15) of a 16-token x 64-channel block.
+constexpr int FIN_TOK = 16;   // tokens per finish block: one per row lane, so a thread has a single batch of slab loads in flight
 __global__ __launch_bounds__(256) void k_conv_finish(const ConvArgs a) {
     __shared__ double s_st[3][64][2];
     const int tid = threadIdx.x;
@@ -561,7 +583,7 @@ __global__ __launch_bounds__(256) void k_conv_finish(const ConvArgs a) {
     const int cq = tid & 15, rl = tid >> 4;
     const int b = blockIdx.z;
     const int n = blockIdx.x * 64 + cq * 4;
-    const int tok_lo = blockIdx.y * 64, tok_hi = min(a.Lout, tok_lo + 64);
+    const int tok_lo = blockIdx.y * FIN_TOK, tok_hi = min(a.Lout, tok_lo + FIN_TOK);
     double s[3][4], ss[3][4];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -657,7 +679,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
         }
     }
     if (forced[0] > 0) {
-        ConvTile t{forced[0], forced[1], forced[2], forced[3]};
+        ConvTile t{forced[0], forced[1], forced[2], forced[3], 0};
         while (t.NW * t.KS > nchunks && t.KS > 1) t.KS /= 2;
         while (t.NW * t.KS > nchunks && t.NW > 1) t.NW /= 2;
         return t;
@@ -670,7 +692,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
     }
     static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
     const int ntaps_guess = 9;
-    ConvTile best{1, 1, 1, 1};
+    ConvTile best{1, 1, 1, 1, 0};
     double best_t = 1e30;
     for (auto& c : cand) {
         const int MT = c[0], NT = c[1];
@@ -696,7 +718,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
                 t += 0.002 * waves / 64;                                              // dispatch cost of very wide grids
                 if (t < best_t - 1e-9) {
                     best_t = t;
-                    best = ConvTile{MT, NT, NW, KS};
+                    best = ConvTile{MT, NT, NW, KS, 0};
                 }
             }
         }
@@ -711,8 +733,10 @@ size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
 template <int MT, int NT, int NW>
 static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t s) {
     const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT);
-    dim3 grid(a.B * tiles, (a.N + 16 * NT - 1) / (16 * NT), a.KS);
-    const size_t smem = conv_smem_bytes(a, ConvTile{MT, NT, NW, a.KS});
+    const int tiles_n = (a.N + 16 * NT - 1) / (16 * NT);
+    const long nblk = a.xmap ? 8L * ((tiles_n * a.KS + 7) / 8) * a.B * tiles : (long)a.B * tiles * tiles_n * a.KS;
+    dim3 grid((unsigned)nblk);
+    const size_t smem = conv_smem_bytes(a, ConvTile{MT, NT, NW, a.KS, 0});
     hipLaunchKernelGGL((k_conv<MT, NT, NW>), grid, dim3(NW * 64), smem, s, a);
     return hipGetLastError();
 }
@@ -757,6 +781,7 @@ hipError_t conv_init_attrs() {
 hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
     ConvArgs a = a0;
     a.KS = t.KS;
+    a.xmap = t.XM;
     if (a.KS > 1 && !a.slab) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
     if (t.MT == 4 && t.NT == 4) e = launch_conv_nw<4, 4>(a, t.NW, s);
@@ -766,7 +791,7 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
     else if (t.MT == 1 && t.NT == 2) e = launch_conv_nw<1, 2>(a, t.NW, s);
     else if (t.MT == 1 && t.NT == 1) e = launch_conv_nw<1, 1>(a, t.NW, s);
     if (e != hipSuccess || a.KS == 1) return e;
-    hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 63) / 64, (a.Lout + 63) / 64, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 63) / 64, (a.Lout + FIN_TOK - 1) / FIN_TOK, a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -147,28 +147,34 @@ hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s) {
 // keys are 16 register values plus two cross-lane steps -- and the P^T registers are directly the
 // B operand of O^T += V^T P^T (K slot g of step s is key 4g+s, exactly the D layout of S^T).
 // q and k are each pre-multiplied by d^-1/4 like the reference.
-template <int D>
-__global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
+template <int D, int QW, int KSP>
+__global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     constexpr int VW = D >= 16 ? 4 : D / 4;        // floats per q/k fragment
     constexpr int NV = D >= 16 ? D / 16 : 1;       // fragments per row
     constexpr int NOB = D >= 16 ? D / 16 : 1;      // 16-row output blocks of O^T
     constexpr int KSTR = D + (D >= 32 ? 4 : 0);    // K row stride in LDS (floats)
-    constexpr int KB = D >= 128 ? 16 : (D >= 64 ? 32 : 64);   // keys per block (LDS budget)
-    constexpr int NKT = KB / 16;
+    constexpr int KB = D >= 128 ? 16 : (D >= 64 ? 32 : (D >= 32 ? 64 : 128));   // keys per block (LDS budget)
+    constexpr int NKT = KB / 16;                   // 16-key tiles per block
+    constexpr int WKT = NKT / KSP;                 // ... of which each wave takes WKT
+    static_assert(WKT >= 1, "key split wider than the key block");
     constexpr int VSTR = KB + 4;                   // V^T row stride: KB keys + 4 (conflict-free b128 reads)
     constexpr int VROWS = D < 16 ? 16 : D;
     constexpr int QPR = D / 4;                     // float4 quads per K/V row
-    constexpr int NLD = (KB * QPR + 255) / 256;    // float4 loads per thread per tile
+    constexpr int NTH = 64 * QW * KSP;
+    constexpr int NLD = (KB * QPR + NTH - 1) / NTH;   // float4 loads per thread per tile
     __shared__ __attribute__((aligned(16))) float Ks[2][KB * KSTR];
     __shared__ __attribute__((aligned(16))) float Vt[2][VROWS * VSTR];
+    constexpr int XW = NOB * 4 + 2;                // merge record per lane: m, l, O^T registers
+    __shared__ float Xo[KSP > 1 ? (KSP - 1) * QW * XW * 64 : 4];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
+    const int qw = wave % QW, kh = wave / QW;      // query tile of the workgroup, key part of each block
     // which (segment, 64-query block)
     int sg = 0;
     while (sg + 1 < a.nseg && (int)blockIdx.x >= a.blk_prefix[sg + 1]) ++sg;
-    const int q0 = (blockIdx.x - a.blk_prefix[sg]) * 64 + wave * 16;
+    const int q0 = (blockIdx.x - a.blk_prefix[sg]) * (16 * QW) + qw * 16;
     const int start = a.seg_start[sg], len = a.seg_len[sg];
     const int h = blockIdx.y, b = blockIdx.z;
     const int RS = 3 * a.C;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
     const float scale = a.scale;
 
     if (D < 16) {   // rows D..15 of V^T are never written: keep them zero (they feed masked MFMA rows)
-        for (int e = tid; e < 2 * VROWS * VSTR; e += 256) (&Vt[0][0])[e] = 0.f;
+        for (int e = tid; e < 2 * VROWS * VSTR; e += NTH) (&Vt[0][0])[e] = 0.f;
         __syncthreads();
     }
 
@@ -194,12 +200,12 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
     for (int o = 0; o < NOB; ++o) oacc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, lsum = 0.f;
 
-    // staging: thread -> (key, quad) of the 64 x D tile
+    // staging: thread -> (key, quad) of the KB x D tile
     f32x4 kreg[NLD], vreg[NLD];
     auto gload = [&](int kb) {
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
-            const int e = tid + 256 * r;
+            const int e = tid + NTH * r;
             const int key = e / QPR, qd = e - key * QPR;
             const bool ok = e < KB * QPR && kb + key < len;
             const float* p = base + (size_t)(start + (ok ? kb + key : 0)) * RS + D + qd * 4;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
-            const int e = tid + 256 * r;
+            const int e = tid + NTH * r;
             const int key = e / QPR, qd = e - key * QPR;
             if (e < KB * QPR) {
                 *reinterpret_cast<f32x4*>(&Ks[buf][key * KSTR + qd * 4]) = kreg[r] * scale;
@@ -229,9 +235,10 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
         if (more) gload(kb + KB);                       // in flight under this block's math
         const float* ks = Ks[buf];
         const float* vt = Vt[buf];
-        f32x4 st[NKT];
+        f32x4 st[WKT];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int w = 0; w < WKT; ++w) {
+            const int kt = kh * WKT + w;
             f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* kp = ks + (kt * 16 + j) * KSTR + VW * g;
 #pragma unroll
@@ -250,25 +257,26 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (kb + kt * 16 + 4 * g + r >= len) s4[r] = -INFINITY;
-            st[kt] = s4;
+            st[w] = s4;
         }
         float mx = st[0][0];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int w = 0; w < WKT; ++w)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[w][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mn = fmaxf(m, mx);
-        const float alpha = __expf(m - mn);
+        const bool live = mn != -INFINITY;              // a key-split wave may see only masked keys so far
+        const float alpha = live ? __expf(m - mn) : 1.0f;
         m = mn;
         float ps = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int w = 0; w < WKT; ++w)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(st[kt][r] - mn);
-                st[kt][r] = p;
+                const float p = live ? __expf(st[w][r] - mn) : 0.f;
+                st[w][r] = p;
                 ps += p;
             }
         lsum = lsum * alpha + ps;
@@ -276,12 +284,13 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
         for (int o = 0; o < NOB; ++o) oacc[o] *= alpha;
         // O^T += V^T P^T : A = V^T rows (d index) x keys, read as 4 consecutive keys per lane
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+        for (int w = 0; w < WKT; ++w) {
+            const int kt = kh * WKT + w;
 #pragma unroll
             for (int o = 0; o < NOB; ++o) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(vt + (16 * o + j) * VSTR + kt * 16 + 4 * g);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) oacc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[s], st[kt][s], oacc[o], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) oacc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[s], st[w][s], oacc[o], 0, 0, 0);
             }
         }
         if (more) lstore(buf ^ 1);
@@ -290,6 +299,34 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
     }
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
+    if constexpr (KSP > 1) {
+        // merge the key parts of each query tile: part kh > 0 parks (m, l, O^T) in LDS
+        float* xo = Xo;                                 // [KSP-1][QW tiles][XW][64 lanes]
+        if (kh > 0) {
+            float* p = xo + ((size_t)((kh - 1) * QW + qw) * XW) * 64 + lane;
+            p[0] = m;
+            p[64] = lsum;
+#pragma unroll
+            for (int o = 0; o < NOB; ++o)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[(2 + o * 4 + r) * 64] = oacc[o][r];
+        }
+        __syncthreads();
+        if (kh > 0) return;
+#pragma unroll
+        for (int k2 = 1; k2 < KSP; ++k2) {
+            const float* p = xo + ((size_t)((k2 - 1) * QW + qw) * XW) * 64 + lane;
+            const float m2 = p[0], l2 = p[64];
+            const float mt = fmaxf(m, m2);
+            const float f1 = __expf(m - mt), f2 = m2 == -INFINITY ? 0.f : __expf(m2 - mt);
+            lsum = lsum * f1 + l2 * f2;
+#pragma unroll
+            for (int o = 0; o < NOB; ++o)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[o][r] = oacc[o][r] * f1 + p[(2 + o * 4 + r) * 64] * f2;
+            m = mt;
+        }
+    }
     const float inv = 1.0f / lsum;
     if (q0 + j < len) {
         float* op = a.out + ((size_t)b * a.L + start + q0 + j) * a.C + (size_t)h * D;
@@ -304,18 +341,32 @@ __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
     }
 }
 
-hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
+    AttnArgs a = a0;
     const int d = a.C / a.H;
-    dim3 grid(a.blk_prefix[a.nseg], a.H, a.B), block(256);
+    // Workgroup shape: QW query tiles (16 queries each) x KSP key parts of every key block.
+    //   long segments : 4 x 2 (8 waves, 2 per SIMD: one wave's softmax VALU overlaps the other's MFMAs)
+    //   short segments: 1 x 4 -- there are too few query tiles to fill 256 CUs, so the keys are split instead
+    long blocks64 = 0;
+    for (int i = 0; i < a.nseg; ++i) blocks64 += (a.seg_len[i] + 63) / 64;
+    const bool wide = blocks64 * a.H * a.B >= 256 || d >= 128;
+    const int qw = wide ? 4 : 1;
+    a.blk_prefix[0] = 0;
+    for (int i = 0; i < a.nseg; ++i) a.blk_prefix[i + 1] = a.blk_prefix[i] + (a.seg_len[i] + 16 * qw - 1) / (16 * qw);
+    dim3 grid(a.blk_prefix[a.nseg], a.H, a.B);
+#define MTV_ATT(D, KS1)                                                                              \
+    if (wide) hipLaunchKernelGGL((k_attention<D, 4, 2>), grid, dim3(512), 0, s, a);                  \
+    else hipLaunchKernelGGL((k_attention<D, 1, KS1>), grid, dim3(64 * KS1), 0, s, a);
     switch (d) {
-        case 4: hipLaunchKernelGGL(k_attention<4>, grid, block, 0, s, a); break;
-        case 8: hipLaunchKernelGGL(k_attention<8>, grid, block, 0, s, a); break;
-        case 16: hipLaunchKernelGGL(k_attention<16>, grid, block, 0, s, a); break;
-        case 32: hipLaunchKernelGGL(k_attention<32>, grid, block, 0, s, a); break;
-        case 64: hipLaunchKernelGGL(k_attention<64>, grid, block, 0, s, a); break;
-        case 128: hipLaunchKernelGGL(k_attention<128>, grid, block, 0, s, a); break;
+        case 4: MTV_ATT(4, 4); break;
+        case 8: MTV_ATT(8, 4); break;
+        case 16: MTV_ATT(16, 4); break;
+        case 32: MTV_ATT(32, 4); break;
+        case 64: MTV_ATT(64, 2); break;
+        case 128: hipLaunchKernelGGL((k_attention<128, 4, 1>), grid, dim3(256), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
+#undef MTV_ATT
     return hipGetLastError();
 }
 

@@ -61,6 +61,7 @@ struct ConvArgs {
     int nstat;
     int KS;                  // >1: cross-workgroup split-K; partial tiles go to `slab`, k_conv_finish completes
     float* slab;             // [KS][B][Lout][N]
+    int xmap;                // ConvTile::XM
     unsigned long long* dbg; // phase timestamps for tools/ubench/conv_bench (nullptr in the product)
 };
 
@@ -112,7 +113,7 @@ struct DdimStep {            // mirror of mtv_ddim_step (include/mtv_hip.h)
 };
 
 // ---- launchers (kernels.hip) ----
-struct ConvTile { int MT, NT, NW, KS; };
+struct ConvTile { int MT, NT, NW, KS, XM; };   // XM: workgroup->tile mapping (0 rows fastest, 1 weight slice per XCD)
 ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn);
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s);   // + k_conv_finish when t.KS > 1

@@ -78,11 +78,11 @@ int main(int argc, char** argv) {
             }
         }
 #endif
-        printf("  tile %d,%d,%d,%d  WGs %5d waves %6d : %8.2f us  %6.1f TF/s  %7.1f GB/s(w)\n", t.MT, t.NT, t.NW, t.KS, tiles * t.KS, tiles * t.KS * t.NW,
+        printf("  tile %d,%d,%d,%d,%d  WGs %5d waves %6d : %8.2f us  %6.1f TF/s  %7.1f GB/s(w)\n", t.MT, t.NT, t.NW, t.KS, t.XM, tiles * t.KS, tiles * t.KS * t.NW,
                us, flops / us / 1e6, wbytes / us / 1e3);
     };
-    if (argc >= 11) {
-        for (int i = 7; i + 3 < argc; i += 4) run(ConvTile{atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]), atoi(argv[i + 3])});
+    if (argc >= 12) {
+        for (int i = 7; i + 4 < argc; i += 5) run(ConvTile{atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]), atoi(argv[i + 3]), atoi(argv[i + 4])});
     } else {
         const int nchunks = ntaps * Cin / 16;
         ConvTile p = conv_pick_tile(1, L, N, nchunks, Cin, gn);
@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
             const int tiles = ((L + 16 * c[0] - 1) / (16 * c[0])) * ((N + 16 * c[1] - 1) / (16 * c[1]));
             const int waves = tiles * NW * KS;
             if (waves < 256 || waves > 8192) continue;
-            run(ConvTile{c[0], c[1], NW, KS});
+            run(ConvTile{c[0], c[1], NW, KS, 0});
         }
     }
     return 0;
