@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8, help="timed oracle steps for the cpu_baseline leg")
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--batched-clips", type=int, default=8,
+                    help="extra, informational: steps/s with this many clips batched on ONE GPU (0 = skip); never `value`")
     args = ap.parse_args()
 
     import ctypes as C
@@ -205,6 +207,45 @@ def main():
                        sample=f"first {args.cpu_steps} of the 250 DDIM steps of the same clip (after warm-up; thread count "
                               f"chosen from {cand} by a 1-step probe, host has {os.cpu_count()} logical CPUs), "
                               f"oracle/ref_unet.py op-for-op PyTorch {torch.__version__} CPU restatement, fp32")
+        # ---- informational only: the same loop with several clips batched on this GPU (amortises the
+        # per-launch floor and the weight stream; NOT the BASELINE workload, never `value`)
+        batched = None
+        if world == 1 and args.batched_clips > 1:
+            Bc = args.batched_clips
+            netb = DiffusionWrapper(UNetModel(**BASE_UNET_CONFIG, frames=T, max_batch=Bc)).eval().to(dev)
+            netb.load_state_dict(net.state_dict())
+            dmb = DDPM(netb, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+            ctxb = netb.diffusion_model.hip_context(dev, Bc)
+            cb = cond.expand(Bc, -1, -1).contiguous()
+            ib = image_cond.expand(Bc, -1, -1).contiguous()
+            nsb = 20
+            nb = torch.randn(nsb, Bc, 4, L, generator=g, device=dev)
+
+            def runb(nsteps):
+                xb = torch.randn(Bc, 4, L, generator=g, device=dev)
+                stp, _ = cycled_steps(dmb, nsteps)
+                _lib.check(lib.mtv_ddim_sample(ctxb, xb.data_ptr(), cb.data_ptr(), ib.data_ptr(), R * R, nb.data_ptr(), nsb,
+                                               stp, nsteps, Bc, C.c_void_p(stream.cuda_stream)), "mtv_ddim_sample")
+
+            runb(3)
+            torch.cuda.synchronize(dev)
+            tb = time.perf_counter()
+            runb(nsb)
+            torch.cuda.synchronize(dev)
+            tb = time.perf_counter() - tb
+            pb = netb.diffusion_model.profile_forward(Bc, 3, dev)
+            cms = sum(p["ms"] for p in pb if p["name"].startswith("conv"))
+            cfl = sum(p["flops"] for p in pb if p["name"].startswith("conv"))
+            ams = sum(p["ms"] for p in pb if p["name"].startswith("attn"))
+            afl = sum(p["flops"] for p in pb if p["name"].startswith("attn"))
+            batched = dict(clips_per_gpu=Bc, steps=nsb, clip_steps_per_s=round(Bc * nsb / tb, 2), ms_per_batched_step=round(1e3 * tb / nsb, 3),
+                           k_conv_tflops=round(cfl / cms / 1e9, 2), k_conv_frac_of_f32_mfma_peak=round(cfl / cms / 1e9 / MFMA_F32_PEAK_TF, 3),
+                           k_attention_tflops=round(afl / ams / 1e9, 2),
+                           k_attention_frac_of_f32_mfma_peak=round(afl / ams / 1e9 / MFMA_F32_PEAK_TF, 3))
+            del netb, dmb
+        attn_roof = dict(bound="mfma", kernel="k_attention", achieved=round(attn["flops"] / (attn["ms"] * 1e-3) / 1e12, 3) if attn["ms"] else 0.0,
+                         peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches_per_step=attn["launches"], flops_per_step=attn["flops"])
+        attn_roof["frac"] = round(attn_roof["achieved"] / MFMA_F32_PEAK_TF, 4)
         result = {
             "metric": "denoise-steps/sec (16-frame 256^2 clip, 250 DDIM steps)",
             "value": round(world * K / dt, 3),
@@ -227,6 +268,8 @@ def main():
             "launches_per_step": work["n_launches"] + 2,
             "flops_per_step": {k: work[k] for k in ("flops_conv3x3", "flops_1x1", "flops_attn_core", "flops_linear")},
             "families": families,
+            "roofline_attention": attn_roof,
+            "batched_info": batched,
         }
     barrier()
     if rank == 0:

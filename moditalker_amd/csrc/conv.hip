@@ -22,8 +22,8 @@
 // grid.y = N / 16NT column tiles, grid.z = KS cross-workgroup K slices; the NW waves of a
 // workgroup split their K range further.  K = (tap, 16-channel chunk) pairs; each wave walks its
 // chunk range with a two-deep register pipeline (loads of chunk i+1 in flight under the MFMAs of
-// chunk i).  Waves are summed by a fixed-order LDS tree (deterministic); with KS > 1 the partial
-// tiles go to a slab and k_conv_finish adds them in fixed order.
+// chunk i).  Waves are summed in LDS in fixed order (deterministic); with KS > 1 the partial tiles go
+// to a slab and the slice that finishes last adds them in fixed order inside the same launch.
 #include <cstdio>
 #include <cstdlib>
 
@@ -481,17 +481,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     MTV_STAMP(4);
     // ---- pass 1 (row-major over the tile): epilogue + coalesced store
     constexpr int QPR = COLS / 4, QUADS = ROWS * QPR;
-    const bool want_stats = a.nstat > 0 && a.KS == 1;
+    const bool want_stats = a.nstat > 0;
     float* fin = ONE_STAGE ? red + (size_t)NW * TILE_REGS * 64 : red;   // (row, col) image of the finished tile for pass 2
-    for (int e = tid; e < QUADS; e += NTH) {
-        const int rr = e / QPR, cq = e - rr * QPR;
-        const int tok = tok0 + rr, n = n0 + cq * 4;
-        if (tok >= a.Lout || n >= a.N) continue;
-        f32x4 v;
+    auto tile_quad = [&](int rr, int cq) -> f32x4 {                     // this workgroup's (partial) result for one quad
         if constexpr (ONE_STAGE) {
             // element (rr, 4cq+k) of wave w sits at w*TILE + ((mt*NT+nb)*4 + r)*64 + lane(i, q)
             const int mt = rr >> 4, qq = (rr >> 2) & 3, r = rr & 3;
-            v = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < NW; ++w)
 #pragma unroll
@@ -499,15 +495,63 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
                     const int col = cq * 4 + k, ii = col / NT, nb = col - ii * NT;
                     v[k] += red[(size_t)w * TILE_REGS * 64 + ((mt * NT + nb) * 4 + r) * 64 + qq * 16 + ii];
                 }
+            return v;
         } else {
-            v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
+            return *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
         }
+    };
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    const size_t sstride = (size_t)a.B * a.Lout * a.N;                  // floats between K slices of the slab
+    if (a.KS > 1) {
+        // Cross-workgroup split-K, completed INSIDE this launch (cdna_hip_programming.md G16, form R1):
+        // every slice parks its partial tile in the slab with WRITE-THROUGH (sc1) 8-byte stores, drains
+        // them, then ONE lane takes a ticket; the slice that draws the last ticket re-reads all KS partials
+        // (sc1 loads: L2/fabric-served, never a stale L1 line) and runs the epilogue.  Sum order is fixed
+        // (slice 0..KS-1), so the result does not depend on which slice finishes last.  (N % 4 == 0 here.)
+        for (int e = tid; e < QUADS; e += NTH) {
+            const int rr = e / QPR, cq = e - rr * QPR;
+            const int tok = tok0 + rr, n = n0 + cq * 4;
+            if (tok >= a.Lout || n >= a.N) continue;
+            const f32x4 v = tile_quad(rr, cq);
+            gu64* dst = (gu64*)(unsigned long long)(a.slab + (size_t)bz * sstride + ((size_t)b * a.Lout + tok) * a.N + n);
+            __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+        __syncthreads();
+        __shared__ int s_last[4];
+        int* ticket = a.tickets + ((size_t)b * tiles_per_b + (tok0 / ROWS)) * tiles_n + by;
+        if (tid == 0) s_last[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.KS - 1;
+        __syncthreads();
+        if (!s_last[0]) return;
+        if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning for the next launch
+    }
+    for (int e = tid; e < QUADS; e += NTH) {
+        const int rr = e / QPR, cq = e - rr * QPR;
+        const int tok = tok0 + rr, n = n0 + cq * 4;
+        if (tok >= a.Lout || n >= a.N) continue;
+        f32x4 v;
         if (a.KS > 1) {
-            float* dst = a.slab + (((size_t)bz * a.B + b) * a.Lout + tok) * a.N + n;
-            if (n + 3 < a.N) *reinterpret_cast<f32x4*>(dst) = v;
-            else
-                for (int k = 0; k < 4 && n + k < a.N; ++k) dst[k] = v[k];
-            continue;
+            gu64* src = (gu64*)(unsigned long long)(a.slab + ((size_t)b * a.Lout + tok) * a.N + n);
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < a.KS; k0 += 8) {      // up to 16 loads in flight, then a fixed-order sum
+                unsigned long long t0[8], t1[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool in = k0 + k < a.KS;
+                    t0[k] = in ? __hip_atomic_load(src + (size_t)(k0 + k) * (sstride / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    t1[k] = in ? __hip_atomic_load(src + (size_t)(k0 + k) * (sstride / 2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[0] += __uint_as_float((unsigned)t0[k]);
+                    v[1] += __uint_as_float((unsigned)(t0[k] >> 32));
+                    v[2] += __uint_as_float((unsigned)t1[k]);
+                    v[3] += __uint_as_float((unsigned)(t1[k] >> 32));
+                }
+            }
+        } else {
+            v = tile_quad(rr, cq);
         }
         const int rs = (a.res && a.gather_skip) ? a.gather_skip[tok] : tok;   // (the LDS index table is gone by now)
 #pragma unroll
@@ -568,91 +612,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     }
 }
 
-// Completes a cross-workgroup split-K convolution: out = sum_ks slab[ks] (+ bias, residual), in fixed
-// order, plus the output's GroupNorm statistics.  grid (ceil(N/64), ceil(Lout/16), B), 256 threads:
-// thread = (row lane 0..15, channel quad 0..15) of a 16-token x 64-channel block.
-constexpr int FIN_TOK = 16;   // tokens per finish block: one per row lane, so a thread has a single batch of slab loads in flight
-__global__ __launch_bounds__(256) void k_conv_finish(const ConvArgs a) {
-    __shared__ double s_st[3][64][2];
-    const int tid = threadIdx.x;
-#if MTV_ABLATE & 64
-    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) a.dbg[6] = __builtin_amdgcn_s_memtime();
-#endif
-    for (int e = tid; e < 3 * 64 * 2; e += 256) (&s_st[0][0][0])[e] = 0.0;
-    __syncthreads();
-    const int cq = tid & 15, rl = tid >> 4;
-    const int b = blockIdx.z;
-    const int n = blockIdx.x * 64 + cq * 4;
-    const int tok_lo = blockIdx.y * FIN_TOK, tok_hi = min(a.Lout, tok_lo + FIN_TOK);
-    double s[3][4], ss[3][4];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s[g][k] = ss[g][k] = 0.0;
-    if (n < a.N) {
-        for (int tok = tok_lo + rl; tok < tok_hi; tok += 16) {
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            const size_t sstride = (size_t)a.B * a.Lout * a.N;
-            const float* src0 = a.slab + ((size_t)b * a.Lout + tok) * a.N + n;
-            if (n + 3 < a.N) {
-                // up to 16 slab loads in flight (the slabs were written by other CUs: each load is an
-                // L2/fabric round trip), then a fixed-order sum
-                for (int k0 = 0; k0 < a.KS; k0 += 16) {
-                    f32x4 t[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        t[k] = k0 + k < a.KS ? *reinterpret_cast<const f32x4*>(src0 + (size_t)(k0 + k) * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) v += t[k];
-                }
-            } else {
-                for (int ks = 0; ks < a.KS; ++ks)
-                    for (int k = 0; k < 4 && n + k < a.N; ++k) v[k] += src0[(size_t)ks * sstride + k];
-            }
-            const int rs = (a.res && a.gather_skip) ? a.gather_skip[tok] : tok;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (n + k < a.N) v[k] = epi(a, v[k], b, tok, rs, n + k);
-            if (!a.out_cm && n + 3 < a.N) {
-                *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
-            } else {
-                for (int k = 0; k < 4 && n + k < a.N; ++k) {
-                    if (a.out_cm) a.out[((size_t)b * a.N + n + k) * a.Lout + tok] = v[k];
-                    else a.out[((size_t)b * a.Lout + tok) * a.N + n + k] = v[k];
-                }
-            }
-            const int sg = seg_of(a.seg_out, tok);
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                if (g == sg) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        s[g][k] += (double)v[k];
-                        ss[g][k] += (double)v[k] * v[k];
-                    }
-                }
-        }
-    }
-#if MTV_ABLATE & 64
-    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) a.dbg[7] = __builtin_amdgcn_s_memtime();
-#endif
-    if (a.nstat == 0) return;
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (ss[g][k] != 0.0) {
-                atomicAdd(&s_st[g][cq * 4 + k][0], s[g][k]);
-                atomicAdd(&s_st[g][cq * 4 + k][1], ss[g][k]);
-            }
-    __syncthreads();
-    for (int e = tid; e < 3 * 64; e += 256) {
-        const int g = e >> 6, c = e & 63;
-        const int nn = blockIdx.x * 64 + c;
-        if (nn < a.N && s_st[g][c][1] != 0.0) stat_add(a, b, g, nn, s_st[g][c][0], s_st[g][c][1]);
-    }
-}
-
 // --------------------------------------------------------------------------------------------
 // tile / split selection: a small analytic cost model (times in microseconds)
 // --------------------------------------------------------------------------------------------
@@ -684,7 +643,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
         while (t.NW * t.KS > nchunks && t.NW > 1) t.NW /= 2;
         return t;
     }
-    static double lat_us = -1.0, fin_us = 2.5;
+    static double lat_us = -1.0, fin_us = 3.0;
     if (lat_us < 0) {
         lat_us = 0.7;
         if (const char* e = getenv("MTV_LAT_US")) lat_us = atof(e);
@@ -704,7 +663,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
             if (NW == 16 && MT * NT >= 8) continue;                   // 1024-thread blocks cap VGPRs at 128: these spill
             for (int KS = 1; KS <= 16; KS *= 2) {
                 const int slices = NW * KS;
-                if (slices > nchunks) continue;
+                if (slices > nchunks || (KS > 1 && (N & 3))) continue;
                 const double waves = tiles * slices;
                 const double cps = (double)nchunks / slices;
                 const double t_mfma = tiles * nchunks * (4.0 * MT * NT) * 32.0 / (waves < 1024 ? waves : 1024.0) / 2400.0;
@@ -713,8 +672,8 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
                 double t = t_mfma > t_lat ? t_mfma : t_lat;
                 t = t > t_l2 ? t : t_l2;
                 t += 2.0 + 0.15 * (NW > 1 ? __builtin_ctz(NW) : 0);
-                if (KS > 1)   // slab round trip (write + KS-fold read) + the finish launch
-                    t += fin_us + (double)(KS + 1) * B * Lout * N * 4.0 / 3e6 + 0.1 * KS;
+                if (KS > 1)   // slab round trip (write + KS-fold read by the last slice) + ticket
+                    t += fin_us + (double)(KS + 1) * B * Lout * N * 4.0 / 3e6 + 0.05 * KS;
                 t += 0.002 * waves / 64;                                              // dispatch cost of very wide grids
                 if (t < best_t - 1e-9) {
                     best_t = t;
@@ -782,7 +741,7 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
     ConvArgs a = a0;
     a.KS = t.KS;
     a.xmap = t.XM;
-    if (a.KS > 1 && !a.slab) return hipErrorInvalidValue;
+    if (a.KS > 1 && (!a.slab || !a.tickets || (a.N & 3))) return hipErrorInvalidValue;
     hipError_t e = hipErrorInvalidValue;
     if (t.MT == 4 && t.NT == 4) e = launch_conv_nw<4, 4>(a, t.NW, s);
     else if (t.MT == 2 && t.NT == 4) e = launch_conv_nw<2, 4>(a, t.NW, s);
@@ -790,9 +749,7 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
     else if (t.MT == 2 && t.NT == 2) e = launch_conv_nw<2, 2>(a, t.NW, s);
     else if (t.MT == 1 && t.NT == 2) e = launch_conv_nw<1, 2>(a, t.NW, s);
     else if (t.MT == 1 && t.NT == 1) e = launch_conv_nw<1, 1>(a, t.NW, s);
-    if (e != hipSuccess || a.KS == 1) return e;
-    hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 63) / 64, (a.Lout + FIN_TOK - 1) / FIN_TOK, a.B), dim3(256), 0, s, a);
-    return hipGetLastError();
+    return e;
 }
 
 }  // namespace mtv

@@ -59,7 +59,8 @@ struct ConvArgs {
     SegInfo seg_out;         // plane boundaries of the output token axis (for the statistics)
     StatOut stat[2];
     int nstat;
-    int KS;                  // >1: cross-workgroup split-K; partial tiles go to `slab`, k_conv_finish completes
+    int KS;                  // >1: cross-workgroup split-K; partial tiles go to `slab`, the last slice completes
+    int* tickets;            // [B * row tiles * column tiles] arrival counters (zero between launches)
     float* slab;             // [KS][B][Lout][N]
     int xmap;                // ConvTile::XM
     unsigned long long* dbg; // phase timestamps for tools/ubench/conv_bench (nullptr in the product)
@@ -116,7 +117,7 @@ struct DdimStep {            // mirror of mtv_ddim_step (include/mtv_hip.h)
 struct ConvTile { int MT, NT, NW, KS, XM; };   // XM: workgroup->tile mapping (0 rows fastest, 1 weight slice per XCD)
 ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn);
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t);
-hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s);   // + k_conv_finish when t.KS > 1
+hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s);
 hipError_t conv_init_attrs();
 hipError_t launch_gn_stats(const StatsArgs& a, hipStream_t s);
 hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s);

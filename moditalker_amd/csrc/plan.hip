@@ -754,6 +754,16 @@ struct Builder {
             if (!slab) return fail(MTV_ERR_HIP, "slab allocation failed");
             c->slab_floats[B] = need;
             for (auto& op : plan->convs) op->a.slab = slab;
+            // arrival counters of the in-launch split-K completion: one per 16x16 output tile (the finest tiling),
+            // zeroed once here; every launch leaves them at zero again
+            size_t nt = 0;
+            for (auto& op : plan->convs) nt += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
+            int* tk = (int*)c->buf("tickets.B" + std::to_string(B), nt);
+            if (!tk) return fail(MTV_ERR_HIP, "ticket allocation failed");
+            for (auto& op : plan->convs) {
+                op->a.tickets = tk;
+                tk += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
+            }
         }
         if (c->accounting) c->work.n_launches = (int)plan->ops.size();
         return MTV_OK;
@@ -827,7 +837,7 @@ static int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                     if (NW == 16 && MT * NT >= 8) continue;
                     for (int KS = 1; KS <= 16; KS *= 2) {
                         if (NW * KS > nchunks) continue;
-                        if (KS > 1 && (size_t)KS * a.B * a.Lout * a.N > slab_cap) continue;
+                        if (KS > 1 && ((size_t)KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) continue;
                         const long waves = tiles * NW * KS;
                         if (waves > 16384 || (waves < 512 && tiles * KS < 64 && NW * KS * 2 <= nchunks && NW < 16)) continue;
                         for (int XM = 0; XM < 2; ++XM) {

@@ -183,6 +183,25 @@ def test_batch_elements_are_independent():
     assert _maxabs(again, one.cpu()) == 0.0
 
 
+def test_repeated_forwards_are_bit_identical():
+    """The cross-workgroup split-K completion (tickets + write-through slab) must never read a stale
+    partial: 30 forwards of the base model on the same inputs are bit-equal (any staleness shows up
+    as a run-to-run difference), and so are two DDIM runs."""
+    net = _build(BASE_CFG, 7, max_batch=1)
+    dev = _dev()
+    x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+    t = torch.tensor([321], device=dev)
+    ref = net(x.to(dev), cond.to(dev), ic.to(dev), t).clone()
+    for _ in range(30):
+        out = net(x.to(dev), cond.to(dev), ic.to(dev), t)
+        assert torch.equal(out, ref)
+    dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=10, w=0.0).to(dev)
+    noise = [z.to(dev) for z in filler.noise_list(10, (1, 4, 2048), seed=7, tag="rep")]
+    za = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=noise)
+    zb = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=noise)
+    assert torch.equal(za, zb)
+
+
 def test_image_cond_tail_is_ignored():
     """Only the first R*R tokens of image_cond are read (unet.py:1022-1025)."""
     net = _build(NARROW_CFG, 11)

@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     a.Lout = L; a.Lsrc = L; a.Lskip = L; a.B = 1; a.W = W; a.ldw = ldw; a.N = N; a.bias = bias; a.out = out; a.seg_src = seg; a.seg_out = seg;
     a.slab = slab;
     CK(hipMalloc(&a.dbg, 4096)); CK(hipMemset(a.dbg, 0, 4096));
+    CK(hipMalloc(&a.tickets, 1 << 20)); CK(hipMemset(a.tickets, 0, 1 << 20));
     if (gn) a.gn = GnIn{sums, gamma, beta, nullptr, 0, Cin / 32, 0, 1};
     const double flops = 2.0 * L * N * (double)ntaps * Cin;
     const double wbytes = 4.0 * ntaps * Cin * N;
@@ -73,7 +74,6 @@ int main(int argc, char** argv) {
                 printf("    blk(y%d,z%d) phases(clk): seg %5lld  prologue %5lld  kloop %6lld  wait+tree %6lld  epilogue %5lld | start+%lld", blk >> 1, blk & 1,
                        (long long)(st[blk * 8 + 1] - st[blk * 8]), (long long)(st[blk * 8 + 2] - st[blk * 8 + 1]), (long long)(st[blk * 8 + 3] - st[blk * 8 + 2]),
                        (long long)(st[blk * 8 + 4] - st[blk * 8 + 3]), (long long)(st[blk * 8 + 5] - st[blk * 8 + 4]), (long long)(st[blk * 8] - st[0]));
-                if (blk == 0 && t.KS > 1) printf("  finish: starts +%lld after main end, runs %lld", (long long)(st[6] - st[5]), (long long)(st[7] - st[6]));
                 printf("\n");
             }
         }
