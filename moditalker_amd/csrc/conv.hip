@@ -92,14 +92,23 @@ __device__ __forceinline__ void enter_segment_u(Cursor<MT>& k, const SegDesc* se
     k.wbase = (gchar*)(unsigned long long)W + (size_t)(crow + c) * (size_t)ldw * 4;
 }
 
-// per-lane half: byte offsets of this lane's A rows for the segment's tap (needs the index table)
+// per-lane half: byte offsets of this lane's A rows for the segment's tap.  Normally read from the LDS
+// index table; `ident` (no gather tables at all: 1x1 convs) derives them from the token index, which
+// needs no memory at all -- such convs start their A loads before the prologue.
 template <int MT>
-__device__ __forceinline__ void enter_segment_rows(Cursor<MT>& k, const SegDesc* segs, const int* idx, int rows, int b, int i, int q) {
+__device__ __forceinline__ void enter_segment_rows(Cursor<MT>& k, const SegDesc* segs, const int* idx, int rows, int b, int i, int q,
+                                                   bool ident, int tok0, int Lout, const SegInfo& sgi) {
     const SegDesc* d = segs + k.seg;
     const int Cp = usgpr(d->Cp), Ls = usgpr(d->Ls), tap = usgpr(d->tap);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int e = idx[tap * rows + 16 * mt + i];
+        int e;
+        if (ident) {
+            const int tok = tok0 + 16 * mt + i;
+            e = tok < Lout ? (k.skip ? tok : (tok | (seg_of(sgi, tok) << 28))) : -1;
+        } else {
+            e = idx[tap * rows + 16 * mt + i];
+        }
         k.e[mt] = e;
         const unsigned st = e < 0 ? 0u : (unsigned)(e & 0x0FFFFFFF);   // padded rows read a valid address, zeroed later
         k.rowoff[mt] = (((unsigned)b * (unsigned)Ls + st) * (unsigned)Cp + 4u * q) * 4u;
@@ -197,7 +206,7 @@ __device__ __forceinline__ float epi(const ConvArgs& a, float v, int b, int tok,
 __device__ __forceinline__ void stat_add(const ConvArgs& a, int b, int sg, int n, double s, double ss) {
     for (int t = 0; t < a.nstat; ++t) {
         const int g = (a.stat[t].coff + n) / a.stat[t].gs;
-        double* dst = a.stat[t].sums + (((size_t)b * 3 + sg) * 32 + g) * 2;
+        double* dst = a.stat[t].sums + (size_t)(blockIdx.x & (STAT_COPIES - 1)) * a.stat_cstride + (((size_t)b * 3 + sg) * 32 + g) * 2;
         atomicAdd(dst, s);
         atomicAdd(dst + 1, ss);
     }
@@ -278,9 +287,31 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     const unsigned ldw4 = (unsigned)ldw * 4u;
     const unsigned woff = (4u * q * (unsigned)ldw + (unsigned)(n0 + NT * i)) * 4u;
     // chunks in flight per wave, bounded by the register budget (1024-thread blocks get 128 VGPRs)
-    constexpr int DEPTH = NW == 16 ? (MT * NT >= 8 ? 2 : (MT * NT >= 4 ? 3 : 4)) : (MT * NT >= 16 ? 2 : (MT * NT >= 8 ? 3 : 4));
+    constexpr int DEPTH = NW == 16 ? (MT * NT >= 4 ? 2 : (MT * NT >= 2 ? 3 : 4)) : (MT * NT >= 16 ? 2 : (MT * NT >= 8 ? 3 : 4));
     Cursor<MT> cur;
     Raw<MT, NT> ring[DEPTH];
+    const bool ident = a.gather == nullptr && a.gather_skip == nullptr;
+    const int Lout_ = a.Lout;
+    const SegInfo sgi = a.seg_src;
+    auto advance = [&]() {
+        cur.c += 16;
+        if (cur.c < cur.cend) {
+            cur.abase += 64;
+            cur.wbase += (size_t)64 * (size_t)ldw;
+        } else {
+            cur.seg += 1;
+            enter_segment_u<MT>(cur, segs, Wp, ldw, 0);
+            enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, ident, tok0, Lout_, sgi);
+        }
+    };
+    auto fill_ring = [&]() {                 // slots 1..DEPTH-1 (slot 0 is loaded separately)
+#pragma unroll
+        for (int d = 1; d < DEPTH; ++d)
+            if (d < ch1 - ch0) {
+                advance();
+                load_chunk<MT, NT>(cur, woff, ldw4, ring[d]);
+            }
+    };
     if (ch0 < ch1) {
         int seg = 0, left = ch0;
         while (seg + 1 < nseg) {
@@ -292,6 +323,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         cur.seg = seg;
         enter_segment_u<MT>(cur, segs, Wp, ldw, left << 4);
         load_b<MT, NT>(cur, woff, ldw4, ring[0]);
+        if (ident) {                         // no index table needed: the whole ring starts now
+            enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, true, tok0, Lout_, sgi);
+            load_a<MT, NT>(cur, ring[0]);
+            fill_ring();
+        }
     }
 
     MTV_STAMP(1);
@@ -327,15 +363,22 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         if (tid * PER < Cmain) fetch(tid * PER);
         for (int e = tid; e < 96; e += NTH) {
             const int sg = e >> 5, g = e & 31;
-            const double* S = a.gn.sums + (size_t)b * 192;
-            double s, ss, n;
+            double s = 0.0, ss = 0.0, n;
             if (a.gn.whole) {
-                s = S[g * 2] + S[64 + g * 2] + S[128 + g * 2];
-                ss = S[g * 2 + 1] + S[64 + g * 2 + 1] + S[128 + g * 2 + 1];
+#pragma unroll
+                for (int k = 0; k < STAT_COPIES; ++k) {
+                    const double* S = a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192;
+                    s += S[g * 2] + S[64 + g * 2] + S[128 + g * 2];
+                    ss += S[g * 2 + 1] + S[64 + g * 2 + 1] + S[128 + g * 2 + 1];
+                }
                 n = (double)a.seg_src.L * a.gn.gs;
             } else {
-                s = S[sg * 64 + g * 2];
-                ss = S[sg * 64 + g * 2 + 1];
+#pragma unroll
+                for (int k = 0; k < STAT_COPIES; ++k) {
+                    const double* S = a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192;
+                    s += S[sg * 64 + g * 2];
+                    ss += S[sg * 64 + g * 2 + 1];
+                }
                 const int len = sg == 0 ? a.seg_src.b1 : (sg == 1 ? a.seg_src.b2 - a.seg_src.b1 : a.seg_src.L - a.seg_src.b2);
                 n = (double)len * a.gn.gs;
             }
@@ -371,29 +414,34 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (ch0 < ch1) {
-        enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q);
-        load_a<MT, NT>(cur, ring[0]);
-        auto advance = [&]() {
-            cur.c += 16;
-            if (cur.c < cur.cend) {
-                cur.abase += 64;
-                cur.wbase += (size_t)64 * (size_t)ldw;
-            } else {
-                cur.seg += 1;
-                enter_segment_u<MT>(cur, segs, Wp, ldw, 0);
-                enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q);
+    // epilogue operands of this thread's first quad are requested now, so their latency hides under the K loop
+    constexpr int QPR0 = COLS / 4;
+    f32x4 pre_bias = f32x4{0.f, 0.f, 0.f, 0.f}, pre_res = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool pre_ok = false;
+    {
+        const int rr = tid / QPR0, cq = tid - rr * QPR0;
+        const int tok = tok0 + rr, n = n0 + cq * 4;
+        if (NW < 16 && a.KS == 1 && rr < ROWS && tok < a.Lout && n + 3 < a.N) {   // (1024-thread blocks have no registers to spare)
+            pre_ok = true;
+            pre_bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.bias2) pre_bias += *reinterpret_cast<const f32x4*>(a.bias2 + n);
+            if (a.bias_b) pre_bias += *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + n);
+            if (a.res) {
+                const int rs = a.gather_skip ? a.gather_skip[tok] : tok;
+                pre_res = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + rs) * a.N + n);
             }
-        };
+        }
+    }
+
+    if (ch0 < ch1) {
+        if (!ident) {
+            enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, false, tok0, Lout_, sgi);
+            load_a<MT, NT>(cur, ring[0]);
+            fill_ring();
+        }
         // ring of DEPTH chunks in flight.  Steady state has no conditionals, so every ring slot keeps
         // fixed registers and the loads of the next DEPTH-1 chunks stay in flight under the MFMAs.
         int n = ch1 - ch0;                       // chunks not yet multiplied (ring slot 0 holds the first)
-#pragma unroll
-        for (int d = 1; d < DEPTH; ++d)
-            if (d < n) {
-                advance();
-                load_chunk<MT, NT>(cur, woff, ldw4, ring[d]);
-            }
         while (n >= 2 * DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -553,10 +601,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         } else {
             v = tile_quad(rr, cq);
         }
-        const int rs = (a.res && a.gather_skip) ? a.gather_skip[tok] : tok;   // (the LDS index table is gone by now)
+        if (pre_ok && e == tid) {
+            // same association as epi(): ((v + bias) + bias2 ...) is replaced by v + (bias + bias2 ...) + res;
+            // a sub-ulp reassociation of the bias terms only
+            v = (v + pre_bias) + pre_res;
+        } else {
+            const int rs = (a.res && a.gather_skip) ? a.gather_skip[tok] : tok;   // (the LDS index table is gone by now)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (n + k < a.N) v[k] = epi(a, v[k], b, tok, rs, n + k);
+            for (int k = 0; k < 4; ++k)
+                if (n + k < a.N) v[k] = epi(a, v[k], b, tok, rs, n + k);
+        }
         if (!a.out_cm && n + 3 < a.N) {
             *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
         } else {
@@ -570,11 +624,19 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     MTV_STAMP(5);
     if (!want_stats) return;
 
-    // ---- pass 2 (column-major over the tile): GroupNorm statistics of the output for its consumers
+    // ---- pass 2 (column-major over the tile): GroupNorm statistics of the output for its consumers.
+    // Rows are reduced with wave shuffles, the channel quads of one group are then combined in LDS, so a
+    // workgroup issues ONE atomic pair per (plane, group, consumer) -- the per-address atomic rate is what
+    // bounds this epilogue (measured: quads of a wide group hitting one address cost 5x the whole kernel).
     __syncthreads();
     constexpr int W = ROWS < 64 ? ROWS : 64;         // lanes that share one channel quad
+    double* qs = reinterpret_cast<double*>(fin + ROWS * LDR);   // [3 planes][QPR quads][2]
     bool fast = true;
     for (int t = 0; t < a.nstat; ++t) fast = fast && ((a.stat[t].gs & 3) == 0);
+    if (fast) {
+        for (int e = tid; e < 3 * QPR * 2; e += NTH) qs[e] = 0.0;
+        __syncthreads();
+    }
     for (int base = 0; base < QUADS; base += NTH) {
         const int e = base + tid;
         const int cq = e / ROWS, rr = e - cq * ROWS;
@@ -594,7 +656,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
                     s += __shfl_xor(s, o);
                     ss += __shfl_xor(ss, o);
                 }
-                if ((lane & (W - 1)) == 0 && e < QUADS && n < a.N) stat_add(a, b, sgi, n, s, ss);
+                // W == 64: one wave per quad (exclusive slot).  W < 64: several waves may hold rows of the
+                // same quad only when ROWS > 64, which never happens (ROWS <= 64) -> exclusive as well.
+                if ((lane & (W - 1)) == 0 && e < QUADS && n < a.N) {
+                    qs[(sgi * QPR + cq) * 2] = s;
+                    qs[(sgi * QPR + cq) * 2 + 1] = ss;
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -610,6 +677,28 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             }
         }
     }
+    if (!fast) return;
+    __syncthreads();
+    // one thread per (consumer, plane, quad): the first quad of each group inside this tile adds up its group
+    for (int e = tid; e < a.nstat * 3 * QPR; e += NTH) {
+        const int t = e / (3 * QPR), r2 = e - t * 3 * QPR;
+        const int sgi = r2 / QPR, cq = r2 - sgi * QPR;
+        const int n = n0 + cq * 4;
+        if (n >= a.N) continue;
+        const int gs = a.stat[t].gs, coff = a.stat[t].coff;
+        const int g = (coff + n) / gs;
+        if (cq > 0 && (coff + n - 4) / gs == g) continue;           // not the first quad of its group in this tile
+        double s = 0.0, ss = 0.0;
+        for (int c2 = cq; c2 < QPR && n0 + c2 * 4 < a.N && (coff + n0 + c2 * 4) / gs == g; ++c2) {
+            s += qs[(sgi * QPR + c2) * 2];
+            ss += qs[(sgi * QPR + c2) * 2 + 1];
+        }
+        if (ss != 0.0) {
+            double* dst = a.stat[t].sums + (size_t)(blockIdx.x & (STAT_COPIES - 1)) * a.stat_cstride + (((size_t)b * 3 + sgi) * 32 + g) * 2;
+            atomicAdd(dst, s);
+            atomicAdd(dst + 1, ss);
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -620,7 +709,7 @@ static size_t lds_bytes(int MT, int NT, int NW, int ntaps, int Cmain, bool has_g
     const size_t idx = (size_t)(((ntaps + 1) * ROWS + 3) & ~3) * 4 + 24 * 32;   // + segment descriptors
     const size_t coef = has_gn ? (size_t)24 * Cmain : 0;
     const size_t part = (size_t)MT * NT * 4 * 64 * 4;                 // one wave's partial tile
-    const size_t fin = (size_t)ROWS * (COLS + 4) * 4;
+    const size_t fin = (size_t)ROWS * (COLS + 4) * 4 + 3 * (COLS / 4) * 2 * 8;   // finished tile + per-quad statistics
     const bool one_stage = NW > 1 && NW * part <= 48 * 1024;
     const size_t redu = one_stage ? NW * part + fin : ((size_t)(NW / 2) * part > fin ? (size_t)(NW / 2) * part : fin);
     size_t r = idx + coef;

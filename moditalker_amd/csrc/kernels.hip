@@ -98,15 +98,21 @@ __global__ __launch_bounds__(256) void k_pool_down(const PoolArgs a) {
     ws = 2 * wd;
     const int c = cq << 2;
     // per-channel GN coefficients from the fp64 sums of this plane
-    const double* S = a.sums + ((size_t)b * 3 + sg) * 64;
+    const double* S0 = a.sums + ((size_t)b * 3 + sg) * 64;
     const int len = sg == 0 ? a.seg_src.b1 : (sg == 1 ? a.seg_src.b2 - a.seg_src.b1 : a.seg_src.L - a.seg_src.b2);
     const double n = (double)len * a.gs;
     float sc[4], bi[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int g = (c + e) / a.gs;
-        const double mean = S[g * 2] / n;
-        double var = S[g * 2 + 1] / n - mean * mean;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < STAT_COPIES; ++k) {
+            s1 += S0[(size_t)k * a.cstride + g * 2];
+            s2 += S0[(size_t)k * a.cstride + g * 2 + 1];
+        }
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         const float rstd = (float)(1.0 / sqrt(var + 1e-5));
         sc[e] = rstd * a.gamma[c + e];

@@ -15,7 +15,7 @@ struct SegInfo {
 // Consumer-side GroupNorm description: statistics live in a per-site table of fp64 (sum, sumsq)
 // per (batch, plane, group); the consumer turns them into per-channel affine coefficients.
 struct GnIn {
-    const double* sums;   // [B][3][32][2] or nullptr (no normalisation)
+    const double* sums;   // [STAT_COPIES][...][B][3][32][2] (copy 0 here, copies `cstride` doubles apart) or nullptr
     const float* gamma;   // [Cmain]
     const float* beta;    // [Cmain]
     const float* film;    // per batch: scale at [c], shift at [Cmain + c]; nullptr = none
@@ -23,13 +23,18 @@ struct GnIn {
     int gs;               // channels per group = Cmain / 32
     int whole;            // 1: statistics over all L tokens (AttentionBlock1D); 0: per plane
     int act;              // 1: SiLU after the affine
+    unsigned cstride;     // doubles between the privatised copies of the statistics arena
 };
 
 // Producer-side GroupNorm statistics: a conv epilogue adds the (sum, sumsq) of its output to the
 // fp64 table of every GN site that will normalise this tensor (possibly as one part of a channel
 // concatenation: `coff` = offset of this tensor's channel 0 in the consumer's channel axis).
+// Producers spread their atomics over STAT_COPIES privatised copies of the table (copy = workgroup id & 7,
+// i.e. normally the XCD it runs on; any choice is correct, consumers add the copies up): 8x fewer atomics
+// per address, and the per-address atomic rate is what bounds a stats epilogue.
+constexpr int STAT_COPIES = 8;
 struct StatOut {
-    double* sums;   // [B][3][32][2]
+    double* sums;   // copy 0 of [B][3][32][2]
     int gs;         // consumer's channels per group
     int coff;
 };
@@ -59,6 +64,7 @@ struct ConvArgs {
     SegInfo seg_out;         // plane boundaries of the output token axis (for the statistics)
     StatOut stat[2];
     int nstat;
+    unsigned stat_cstride;   // doubles between the copies of the statistics arena
     int KS;                  // >1: cross-workgroup split-K; partial tiles go to `slab`, the last slice completes
     int* tickets;            // [B * row tiles * column tiles] arrival counters (zero between launches)
     float* slab;             // [KS][B][Lout][N]
@@ -66,7 +72,7 @@ struct ConvArgs {
     unsigned long long* dbg; // phase timestamps for tools/ubench/conv_bench (nullptr in the product)
 };
 
-struct StatsArgs {
+struct StatsArgs {   // (fallback pass: writes copy 0 only)
     const float* src[2];
     int C[2];
     int nparts;
@@ -81,6 +87,7 @@ struct PoolArgs {            // ResBlock(down=True): avgpool2x2 of SiLU(GN(x)) a
     float* out_act;          // [B][Ldst][C]
     float* out_x;            // [B][Ldst][C]
     const double* sums;
+    unsigned cstride;
     const float* gamma;
     const float* beta;
     int B, C, gs;

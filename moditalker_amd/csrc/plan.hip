@@ -115,6 +115,7 @@ struct mtv_ctx {
     std::vector<int*> g3, gup3, gup1;           // gather tables per level
     double* stats = nullptr;                     // GN site arena
     size_t stats_bytes = 0;
+    size_t stats_copy_doubles = 0;              // doubles per privatised copy of the arena
     int site_cursor = 0;
     float* freqs = nullptr;
     // external-layout staging (channel-major) and sampler state
@@ -393,6 +394,7 @@ struct Builder {
     void add_conv(ConvArgs a0, const std::string& name, int lvl_out) {
         a0.B = B;
         a0.seg_out = c->lv[lvl_out].seg();
+        a0.stat_cstride = (unsigned)c->stats_copy_doubles;
         const int nchunks = a0.ntaps * (a0.Cmain / 16) + a0.Cskip / 16;
         account_conv(a0);
         auto op = std::make_shared<ConvOp>();
@@ -514,7 +516,7 @@ struct Builder {
             pa.lvl = lvl_out; pa.C = cin; pa.p = c->act(nm + ".pool_act", lvl_out, cin);
             px.lvl = lvl_out; px.C = cin; px.p = c->act(nm + ".pool_x", lvl_out, cin);
             PoolArgs pl{};
-            pl.x = x[0].p; pl.out_act = pa.p; pl.out_x = px.p; pl.sums = site1; pl.gamma = g1; pl.beta = b1;
+            pl.x = x[0].p; pl.out_act = pa.p; pl.out_x = px.p; pl.sums = site1; pl.cstride = (unsigned)c->stats_copy_doubles; pl.gamma = g1; pl.beta = b1;
             pl.B = B; pl.C = cin; pl.gs = cin / 32; pl.seg_src = Li.seg(); pl.seg_dst = Lo.seg(); pl.r_dst = Lo.r; pl.t_dst = Lo.t;
             push("pool_down", [pl](hipStream_t s) { return launch_pool_down(pl, s); });
             a.nmain = 1; a.src[0] = pa.p; a.C[0] = cin;
@@ -527,7 +529,7 @@ struct Builder {
             a.gather = r.updown == 2 ? c->gup3[lvl_out] : c->g3[lvl_out];
             a.Lsrc = Li.L;
             a.seg_src = Li.seg();
-            a.gn = GnIn{site1, g1, b1, nullptr, 0, cin / 32, 0, 1};
+            a.gn = GnIn{site1, g1, b1, nullptr, 0, cin / 32, 0, 1, (unsigned)c->stats_copy_doubles};
         }
         add_conv(a, nm + ".conv1", lvl_out);
 
@@ -554,7 +556,7 @@ struct Builder {
         d.Cmain = r.cout;
         d.gather = c->g3[lvl_out];
         d.seg_src = Lo.seg();
-        d.gn = GnIn{site2, g2, b2, f.use_scale_shift_norm ? film_out + r.film_off : nullptr, c->film_total, r.cout / 32, 0, 1};
+        d.gn = GnIn{site2, g2, b2, f.use_scale_shift_norm ? film_out + r.film_off : nullptr, c->film_total, r.cout / 32, 0, 1, (unsigned)c->stats_copy_doubles};
         if (has_skip_conv) {
             if (r.updown) { err = "up/down block with skip conv"; return Tens{}; }
             d.nskip = (int)x.size();
@@ -597,7 +599,7 @@ struct Builder {
         ConvArgs a{};
         a.ntaps = 1; a.Lout = L.L; a.Lsrc = L.L; a.N = 3 * C; a.W = Wq; a.ldw = ldq; a.bias = bq; a.out = qkv;
         a.nmain = 1; a.src[0] = x.p; a.C[0] = C; a.Cmain = C; a.seg_src = L.seg();
-        a.gn = GnIn{site, gw, gb, nullptr, 0, C / 32, whole ? 1 : 0, 0};
+        a.gn = GnIn{site, gw, gb, nullptr, 0, C / 32, whole ? 1 : 0, 0, (unsigned)c->stats_copy_doubles};
         add_conv(a, nm + ".qkv", lvl);
 
         float* att = c->act(nm + ".att", lvl, C);
@@ -736,7 +738,7 @@ struct Builder {
             a.ntaps = 9; a.Lout = L.L; a.Lsrc = L.L; a.N = f.out_channels; a.W = W; a.ldw = ld; a.bias = bias;
             a.out = c->eps; a.out_cm = 1;
             a.nmain = 1; a.src[0] = cur.p; a.C[0] = cur.C; a.Cmain = cur.C; a.gather = c->g3[0]; a.seg_src = L.seg();
-            a.gn = GnIn{site, gw, gb, nullptr, 0, cur.C / 32, 0, 1};
+            a.gn = GnIn{site, gw, gb, nullptr, 0, cur.C / 32, 0, 1, (unsigned)c->stats_copy_doubles};
             add_conv(a, "head", 0);
         }
         if (c->site_cursor > c->n_sites) return fail(MTV_ERR_INVALID, "GN site arena overflow");
@@ -958,7 +960,8 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
         c->gup1.push_back(d1);
     }
     // statistics arena, staging buffers, sampler state
-    c->stats_bytes = (size_t)c->n_sites * cfg->max_batch * 192 * sizeof(double);
+    c->stats_copy_doubles = (size_t)c->n_sites * cfg->max_batch * 192;
+    c->stats_bytes = c->stats_copy_doubles * STAT_COPIES * sizeof(double);
     if ((rc = c->dmalloc((void**)&c->stats, c->stats_bytes)) != MTV_OK) return rc;
     const int L = c->lv[0].L, RR = c->lv[0].b1, mb = cfg->max_batch;
     if ((rc = c->dmalloc((void**)&c->xin, (size_t)mb * 4 * L * 4)) != MTV_OK) return rc;

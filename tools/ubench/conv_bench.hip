@@ -50,6 +50,14 @@ int main(int argc, char** argv) {
     a.slab = slab;
     CK(hipMalloc(&a.dbg, 4096)); CK(hipMemset(a.dbg, 0, 4096));
     CK(hipMalloc(&a.tickets, 1 << 20)); CK(hipMemset(a.tickets, 0, 1 << 20));
+    if (const char* e = getenv("STATS")) {      // STATS="gs0[,gs1]": fused GroupNorm statistics targets
+        int g0 = 0, g1 = 0;
+        const int n = sscanf(e, "%d,%d", &g0, &g1);
+        double* st; CK(hipMalloc(&st, 2 * 192 * 8)); CK(hipMemset(st, 0, 2 * 192 * 8));
+        if (n >= 1 && g0 > 0) a.stat[a.nstat++] = StatOut{st, g0, 0};
+        if (n >= 2 && g1 > 0) a.stat[a.nstat++] = StatOut{st + 192, g1, 0};
+        printf("stats targets: %d (gs %d %d)\n", a.nstat, g0, g1);
+    }
     if (gn) a.gn = GnIn{sums, gamma, beta, nullptr, 0, Cin / 32, 0, 1};
     const double flops = 2.0 * L * N * (double)ntaps * Cin;
     const double wbytes = 4.0 * ntaps * Cin * N;
