@@ -84,39 +84,46 @@ hipError_t launch_gn_stats(const StatsArgs& a, hipStream_t s) {
 // ResBlock(down=True) input path: avgpool2x2(SiLU(GN(x))) and avgpool2x2(x)
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_pool_down(const PoolArgs a) {
-    const int nq = a.C >> 2;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)a.B * a.seg_dst.L * nq;
-    if (idx >= total) return;
-    const int cq = (int)(idx % nq);
-    const int tok = (int)((idx / nq) % a.seg_dst.L);
-    const int b = (int)(idx / ((long)nq * a.seg_dst.L));
-    int sg, y, x, wd, ws, base_s;
-    if (tok < a.seg_dst.b1) { sg = 0; wd = a.r_dst; y = tok / wd; x = tok - y * wd; base_s = 0; }
-    else if (tok < a.seg_dst.b2) { sg = 1; wd = a.r_dst; const int tt = tok - a.seg_dst.b1; y = tt / wd; x = tt - y * wd; base_s = a.seg_src.b1; }
-    else { sg = 2; wd = a.r_dst; const int tt = tok - a.seg_dst.b2; y = tt / wd; x = tt - y * wd; base_s = a.seg_src.b2; }
-    ws = 2 * wd;
-    const int c = cq << 2;
-    // per-channel GN coefficients from the fp64 sums of this plane
-    const double* S0 = a.sums + ((size_t)b * 3 + sg) * 64;
-    const int len = sg == 0 ? a.seg_src.b1 : (sg == 1 ? a.seg_src.b2 - a.seg_src.b1 : a.seg_src.L - a.seg_src.b2);
-    const double n = (double)len * a.gs;
-    float sc[4], bi[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int g = (c + e) / a.gs;
+    // grid (blocks over dst tokens x channel quads, B): one batch element per block row, so the group
+    // statistics (summed over the privatised copies) are finalised once per block into LDS
+    __shared__ float2 s_mr[3][32];
+    const int b = blockIdx.y;
+    for (int e = threadIdx.x; e < 96; e += 256) {
+        const int sg = e >> 5, g = e & 31;
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < STAT_COPIES; ++k) {
-            s1 += S0[(size_t)k * a.cstride + g * 2];
-            s2 += S0[(size_t)k * a.cstride + g * 2 + 1];
+            const double* S = a.sums + (size_t)k * a.cstride + ((size_t)b * 3 + sg) * 64;
+            s1 += S[g * 2];
+            s2 += S[g * 2 + 1];
         }
+        const int len = sg == 0 ? a.seg_src.b1 : (sg == 1 ? a.seg_src.b2 - a.seg_src.b1 : a.seg_src.L - a.seg_src.b2);
+        const double n = (double)len * a.gs;
         const double mean = s1 / n;
         double var = s2 / n - mean * mean;
         var = var < 0.0 ? 0.0 : var;
-        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-        sc[e] = rstd * a.gamma[c + e];
-        bi[e] = a.beta[c + e] - sc[e] * (float)mean;
+        s_mr[sg][g] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
+    }
+    __syncthreads();
+    const int nq = a.C >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.seg_dst.L * nq;
+    if (idx >= total) return;
+    const int cq = (int)(idx % nq);
+    const int tok = (int)(idx / nq);
+    int sg, y, x, base_s;
+    const int wd = a.r_dst;
+    if (tok < a.seg_dst.b1) { sg = 0; y = tok / wd; x = tok - y * wd; base_s = 0; }
+    else if (tok < a.seg_dst.b2) { sg = 1; const int tt = tok - a.seg_dst.b1; y = tt / wd; x = tt - y * wd; base_s = a.seg_src.b1; }
+    else { sg = 2; const int tt = tok - a.seg_dst.b2; y = tt / wd; x = tt - y * wd; base_s = a.seg_src.b2; }
+    const int ws = 2 * wd;
+    const int c = cq << 2;
+    float sc[4], bi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float2 mr = s_mr[sg][(c + e) / a.gs];
+        sc[e] = mr.y * a.gamma[c + e];
+        bi[e] = a.beta[c + e] - sc[e] * mr.x;
     }
     f32x4 sa = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
 #pragma unroll
@@ -137,8 +144,8 @@ __global__ __launch_bounds__(256) void k_pool_down(const PoolArgs a) {
 }
 
 hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s) {
-    const long total = (long)a.B * a.seg_dst.L * (a.C >> 2);
-    hipLaunchKernelGGL(k_pool_down, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    const long total = (long)a.seg_dst.L * (a.C >> 2);
+    hipLaunchKernelGGL(k_pool_down, dim3((unsigned)((total + 255) / 256), a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
