@@ -150,11 +150,34 @@ def main():
                     launches=fam.get("conv3", {}).get("launches", 0) + fam.get("conv1", {}).get("launches", 0))
         attn = fam.get("attn", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         step_ms_events = sum(f["ms"] for f in fam.values())
+        # An event record between two launches costs a few us that rocprofv3 does not see.  Calibrate it
+        # from this run: (sum of the event-bracketed launches) - (timed step) spread over the launches, and
+        # take it off every launch so `avg_launch_us` is the kernel duration rocprofv3 reports
+        # (profiles/r01_step_summary.txt: the two agree to ~1 %).  The raw figures are kept beside it.
+        n_prof = max(1, len(prof))
+        ev_ms = max(0.0, (step_ms_events - 1e3 * dt / K) / n_prof)
+        for f in list(fam.values()) + [conv, attn]:
+            f["ms_raw"] = f["ms"]
+            f["ms"] = max(1e-6, f["ms"] - ev_ms * f["launches"])
         dom_name, dom = ("k_conv", conv) if conv["ms"] >= attn["ms"] else ("k_attention", attn)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        # HBM bytes per launch from the PMC passes (cannot be collected inside this process): the committed
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this same command, gfx950 correction applied
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            e = pmc[dom_name]
+            traffic = round((2.0 * e["fetch_raw_MB_per_step"] + e["write_raw_MB_per_step"]) * 1e6 / e["launches_per_step"])
+            traffic_src = pmc["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TF,
-                        unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TF, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TF, 4), traffic=traffic, traffic_unit="bytes/launch",
+                        traffic_source=traffic_src,
                         launches_per_step=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / max(1, dom["launches"]), 3),
+                        avg_launch_us_with_event_overhead=round(1e3 * dom["ms_raw"] / max(1, dom["launches"]), 3),
+                        event_overhead_us_per_launch=round(1e3 * ev_ms, 3),
+                        algorithmic_bytes_per_launch=round(dom["bytes"] / max(1, dom["launches"])),
                         flops_per_step=dom["flops"],
                         hbm_view=dict(algorithmic_bytes_per_step=dom["bytes"],
                                       achieved_GBs=round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1) if dom["ms"] > 0 else 0.0,

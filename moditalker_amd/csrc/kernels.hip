@@ -367,15 +367,21 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     a.blk_prefix[0] = 0;
     for (int i = 0; i < a.nseg; ++i) a.blk_prefix[i + 1] = a.blk_prefix[i] + (a.seg_len[i] + 16 * qw - 1) / (16 * qw);
     dim3 grid(a.blk_prefix[a.nseg], a.H, a.B);
-#define MTV_ATT(D, KS1)                                                                              \
-    if (wide) hipLaunchKernelGGL((k_attention<D, 4, 2>), grid, dim3(512), 0, s, a);                  \
+    static int wide_ksp = -1;                       // tuning aid: MTV_ATT_KSP=2|4 (key parts of the 4-tile shape)
+    if (wide_ksp < 0) {
+        wide_ksp = 2;   // 4 (1024-thread workgroups) measured equal in time; 2 keeps workgroups at 512 threads
+        if (const char* e = getenv("MTV_ATT_KSP")) wide_ksp = atoi(e) == 4 ? 4 : 2;
+    }
+#define MTV_ATT(D, KS1, KSW)                                                                         \
+    if (wide && KSW == 4 && wide_ksp == 4) hipLaunchKernelGGL((k_attention<D, 4, KSW>), grid, dim3(256 * KSW), 0, s, a); \
+    else if (wide) hipLaunchKernelGGL((k_attention<D, 4, 2>), grid, dim3(512), 0, s, a);             \
     else hipLaunchKernelGGL((k_attention<D, 1, KS1>), grid, dim3(64 * KS1), 0, s, a);
     switch (d) {
-        case 4: MTV_ATT(4, 4); break;
-        case 8: MTV_ATT(8, 4); break;
-        case 16: MTV_ATT(16, 4); break;
-        case 32: MTV_ATT(32, 4); break;
-        case 64: MTV_ATT(64, 2); break;
+        case 4: MTV_ATT(4, 4, 4); break;
+        case 8: MTV_ATT(8, 4, 4); break;
+        case 16: MTV_ATT(16, 4, 4); break;
+        case 32: MTV_ATT(32, 4, 4); break;
+        case 64: MTV_ATT(64, 2, 2); break;
         case 128: hipLaunchKernelGGL((k_attention<128, 4, 1>), grid, dim3(256), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
