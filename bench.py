@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=5)
     ap.add_argument("--batched-clips", type=int, default=8,
                     help="extra, informational: steps/s with this many clips batched on ONE GPU (0 = skip); never `value`")
+    ap.add_argument("--res", type=int, default=32, choices=(32, 64),
+                    help="latent resolution R: 32 = BASELINE configs[1] (the metric's workload), 64 = configs[3] (512x512 clip)")
     args = ap.parse_args()
 
     import ctypes as C
@@ -83,9 +85,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    R, T, S = 32, 16, 250
+    R, T, S = args.res, 16, 250
     L = R * R + 2 * T * R
     K, W = args.steps, args.warmup
+    BASE_UNET_CONFIG = dict(BASE_UNET_CONFIG, image_size=R)
     net = DiffusionWrapper(UNetModel(**BASE_UNET_CONFIG, frames=T, max_batch=1)).eval().to(dev)
     synth_weights_(net, dev, seed=1234)          # same weights on every rank (replica per GPU)
     dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
@@ -157,6 +160,8 @@ def main():
         n_prof = max(1, len(prof))
         ev_ms = max(0.0, (step_ms_events - 1e3 * dt / K) / n_prof)
         for f in list(fam.values()) + [conv, attn]:
+            if "ms_raw" in f:                     # `attn` is fam["attn"] itself
+                continue
             f["ms_raw"] = f["ms"]
             f["ms"] = max(1e-6, f["ms"] - ev_ms * f["launches"])
         dom_name, dom = ("k_conv", conv) if conv["ms"] >= attn["ms"] else ("k_attention", attn)
@@ -282,7 +287,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (random-init weights incl. zero-init tensors, U(-1,1) cond latents, N(0,1) noise)",
-            "config": {"workload": "configs[1]: 16-frame 256x256 clip = tri-plane latent [1,4,2048] (R=32,T=16), "
+            "config": {"workload": f"configs[{1 if R == 32 else 3}]: 16-frame {8 * R}x{8 * R} clip = tri-plane latent [1,4,{L}] (R={R},T=16), "
                                    "base second-stage UNet (132.2M live params), DDIM eta=1, 250-step schedule, B=1 per GPU",
                        "clips": world, "parallelism": f"clip-sharded x{world}, all_gather of latents at the end"},
             "roofline": roofline,

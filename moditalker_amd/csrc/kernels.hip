@@ -12,6 +12,7 @@
 // index of B/D may be permuted freely too.  Both freedoms are used so that every operand fragment
 // is a plain 16-byte global load: no LDS staging of operands is needed at the f32 MFMA rate.
 #include "mtv_internal.h"
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -160,8 +161,20 @@ hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s) {
 // keys are 16 register values plus two cross-lane steps -- and the P^T registers are directly the
 // B operand of O^T += V^T P^T (K slot g of step s is key 4g+s, exactly the D layout of S^T).
 // q and k are each pre-multiplied by d^-1/4 like the reference.
+// max over the lane pairs (l, l^16) / (l, l^32), result in every lane: v_permlane{16,32}_swap_b32 with both
+// operands holding x leaves {x_even_rows, x_odd_rows} / {x_low_half, x_high_half} in the two registers
+__device__ __forceinline__ float lane_swap_max16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float lane_swap_max32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 template <int D, int QW, int KSP>
 __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
+    constexpr float LOG2E = 1.4426950408889634f;
     constexpr int VW = D >= 16 ? 4 : D / 4;        // floats per q/k fragment
     constexpr int NV = D >= 16 ? D / 16 : 1;       // fragments per row
     constexpr int NOB = D >= 16 ? D / 16 : 1;      // 16-row output blocks of O^T
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
 #pragma unroll
         for (int u = 0; u < NV; ++u)
 #pragma unroll
-            for (int e = 0; e < VW; ++e) qreg[u][e] = ok ? qp[16 * u + e] * scale : 0.f;
+            for (int e = 0; e < VW; ++e) qreg[u][e] = ok ? qp[16 * u + e] * scale * LOG2E : 0.f;   // scores in log2 units
     }
     f32x4 oacc[NOB];
 #pragma unroll
@@ -243,9 +256,12 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     lstore(0);
     __syncthreads();
     int buf = 0;
-    for (int kb = 0; kb < len; kb += KB) {
-        const bool more = kb + KB < len;
-        if (more) gload(kb + KB);                       // in flight under this block's math
+    // One key block.  FULL (every key of the block exists -- all blocks but possibly the last) is a separate
+    // instantiation: no per-element masking, no all-masked guard.  Scores are in the log2 domain (log2 e is
+    // folded into q), so p = exp2(s - m) is one subtract + one v_exp_f32 per element; the cross-lane maxima
+    // use the gfx950 lane-swap instructions (VALU, no LDS round trip).
+    auto block = [&](int kb, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const float* ks = Ks[buf];
         const float* vt = Vt[buf];
         f32x4 st[WKT];
@@ -267,9 +283,11 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < VW; ++e) s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[e], qreg[u][e], s4, 0, 0, 0);
             }
+            if constexpr (!FULL) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (kb + kt * 16 + 4 * g + r >= len) s4[r] = -INFINITY;
+                for (int r = 0; r < 4; ++r)
+                    if (kb + kt * 16 + 4 * g + r >= len) s4[r] = -INFINITY;
+            }
             st[w] = s4;
         }
         float mx = st[0][0];
@@ -277,18 +295,18 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         for (int w = 0; w < WKT; ++w)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[w][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = lane_swap_max16(mx);
+        mx = lane_swap_max32(mx);
         const float mn = fmaxf(m, mx);
-        const bool live = mn != -INFINITY;              // a key-split wave may see only masked keys so far
-        const float alpha = live ? __expf(m - mn) : 1.0f;
+        const bool live = FULL || mn != -INFINITY;      // a key-split wave may see only masked keys so far
+        const float alpha = live ? __builtin_amdgcn_exp2f(m - mn) : 1.0f;
         m = mn;
         float ps = 0.f;
 #pragma unroll
         for (int w = 0; w < WKT; ++w)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = live ? __expf(st[w][r] - mn) : 0.f;
+                const float p = live ? __builtin_amdgcn_exp2f(st[w][r] - mn) : 0.f;
                 st[w][r] = p;
                 ps += p;
             }
@@ -306,6 +324,12 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
                 for (int s = 0; s < 4; ++s) oacc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[s], st[w][s], oacc[o], 0, 0, 0);
             }
         }
+    };
+    for (int kb = 0; kb < len; kb += KB) {
+        const bool more = kb + KB < len;
+        if (more) gload(kb + KB);                       // in flight under this block's math
+        if (kb + KB <= len) block(kb, std::true_type{});
+        else block(kb, std::false_type{});
         if (more) lstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -331,7 +355,7 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
             const float* p = xo + ((size_t)((k2 - 1) * QW + qw) * XW) * 64 + lane;
             const float m2 = p[0], l2 = p[64];
             const float mt = fmaxf(m, m2);
-            const float f1 = __expf(m - mt), f2 = m2 == -INFINITY ? 0.f : __expf(m2 - mt);
+            const float f1 = __builtin_amdgcn_exp2f(m - mt), f2 = m2 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m2 - mt);
             lsum = lsum * f1 + l2 * f2;
 #pragma unroll
             for (int o = 0; o < NOB; ++o)

@@ -111,6 +111,29 @@ def test_eager_equals_graph_and_is_deterministic():
     assert _maxabs(a, c.cpu()) <= 1e-6
 
 
+def test_config3_512px_clip_vs_oracle():
+    """BASELINE configs[3]: 16-frame 512x512 clip = (R,T)=(64,16), base UNet, L=6144 tokens.  One forward at a
+    high and a low timestep and a 3-step DDIM against the oracle (the reference hard-wires R=32)."""
+    from oracle import ref_ddpm, ref_unet
+    R, T, S = 64, 16, 3
+    cfg = dict(BASE_CFG, image_size=R)
+    net = _build(cfg, 9, frames=T, max_batch=1)
+    dev = _dev()
+    L = R * R + 2 * T * R
+    x, cond, ic = filler.synthetic_inputs(1, R, T, seed=9, tag="c3")
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    for tv in (999, 3):
+        t = torch.tensor([tv])
+        ref = ref_unet.unet_forward(sd, cfg, x, cond, ic, t, R, T)
+        eps = net(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev))
+        assert _maxabs(eps, ref) <= FWD_TOL, tv
+    noise = filler.noise_list(S, (1, 4, L), seed=9, tag="c3.noise")
+    dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+    z = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=[n.to(dev) for n in noise])
+    zr = ref_ddpm.ddim_sample(lambda a, b, c, d: ref_unet.unet_forward(sd, cfg, a, b, c, d, R, T), cond, ic, noise, S)
+    assert _maxabs(z, zr) <= 1e-3
+
+
 # ----------------------------------------------------------------------------------------------
 # geometries the reference cannot execute (hard-wired 32/16): pinned by the oracle (validated
 # against the reference at (32,16) by tests/golden/make_golden.py)
