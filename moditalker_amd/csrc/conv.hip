@@ -214,6 +214,7 @@ __device__ __forceinline__ void stat_add(const ConvArgs& a, int b, int sg, int n
 
 template <int MT, int NT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
+    touch_kernargs<(int)sizeof(ConvArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float2 s_mr[3][32];
     const int tid = threadIdx.x;
@@ -274,6 +275,36 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         d.skip = skip ? 1 : 0;
         segs[tid] = d;
     }
+    // source-token table.  Identity / arithmetic gathers need no memory, so the table is complete before the
+    // first barrier and the operand ring can start right away; table gathers are fetched during the prologue.
+    const bool ident = a.gather == nullptr && a.gather_skip == nullptr;
+    const bool no_tab = (a.gather == nullptr || a.geo_main != 0) && (a.gather_skip == nullptr || a.geo_skip != 0);
+    auto skip_src = [&](int tok) -> int {
+        if (a.geo_skip) return geo_source(a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF;
+        return a.gather_skip ? a.gather_skip[tok] : tok;
+    };
+    auto build_idx = [&]() {
+        for (int e = tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
+            const int t = e / ROWS, r = e - t * ROWS;
+            const int tok = tok0 + r;
+            int v = -1;
+            if (tok < a.Lout) {
+                if (t < a.ntaps) {
+                    if (a.geo_main) {
+                        const int ky = t / 3;
+                        v = geo_source(a.geo_r, a.geo_t, tok, ky, t - 3 * ky, a.geo_main == 2);
+                    } else {
+                        const int st = a.gather ? a.gather[t * a.Lout + tok] : tok;
+                        v = st < 0 ? -1 : (st | (seg_of(a.seg_src, st) << 28));
+                    }
+                } else {
+                    v = skip_src(tok);
+                }
+            }
+            idx[e] = v;
+        }
+    };
+    if (no_tab && !ident) build_idx();
     __syncthreads();
 
     // ---- this wave's chunk range; the W fragment of its first chunk is requested NOW, so the (HBM-cold)
@@ -290,7 +321,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     constexpr int DEPTH = NW == 16 ? (MT * NT >= 4 ? 2 : (MT * NT >= 2 ? 3 : 4)) : (MT * NT >= 16 ? 2 : (MT * NT >= 8 ? 3 : 4));
     Cursor<MT> cur;
     Raw<MT, NT> ring[DEPTH];
-    const bool ident = a.gather == nullptr && a.gather_skip == nullptr;
     const int Lout_ = a.Lout;
     const SegInfo sgi = a.seg_src;
     auto advance = [&]() {
@@ -323,28 +353,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         cur.seg = seg;
         enter_segment_u<MT>(cur, segs, Wp, ldw, left << 4);
         load_b<MT, NT>(cur, woff, ldw4, ring[0]);
-        if (ident) {                         // no index table needed: the whole ring starts now
-            enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, true, tok0, Lout_, sgi);
+        if (no_tab) {                        // the index table (if any) is ready: the whole ring starts now
+            enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, ident, tok0, Lout_, sgi);
             load_a<MT, NT>(cur, ring[0]);
             fill_ring();
         }
     }
 
     MTV_STAMP(1);
-    for (int e = tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
-        const int t = e / ROWS, r = e - t * ROWS;
-        const int tok = tok0 + r;
-        int v = -1;
-        if (tok < a.Lout) {
-            if (t < a.ntaps) {
-                const int st = a.gather ? a.gather[t * a.Lout + tok] : tok;
-                v = st < 0 ? -1 : (st | (seg_of(a.seg_src, st) << 28));
-            } else {
-                v = a.gather_skip ? a.gather_skip[tok] : tok;
-            }
-        }
-        idx[e] = v;
-    }
+    if (!no_tab) build_idx();
     if (do_gn) {
         // per-channel inputs of the first round are requested BEFORE the statistics are reduced, so
         // the two global-memory latencies overlap
@@ -427,14 +444,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             if (a.bias2) pre_bias += *reinterpret_cast<const f32x4*>(a.bias2 + n);
             if (a.bias_b) pre_bias += *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + n);
             if (a.res) {
-                const int rs = a.gather_skip ? a.gather_skip[tok] : tok;
+                const int rs = skip_src(tok);
                 pre_res = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + rs) * a.N + n);
             }
         }
     }
 
     if (ch0 < ch1) {
-        if (!ident) {
+        if (!no_tab) {
             enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, false, tok0, Lout_, sgi);
             load_a<MT, NT>(cur, ring[0]);
             fill_ring();
@@ -606,7 +623,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             // a sub-ulp reassociation of the bias terms only
             v = (v + pre_bias) + pre_res;
         } else {
-            const int rs = (a.res && a.gather_skip) ? a.gather_skip[tok] : tok;   // (the LDS index table is gone by now)
+            const int rs = a.res ? skip_src(tok) : tok;   // (the LDS index table is gone by now)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (n + k < a.N) v[k] = epi(a, v[k], b, tok, rs, n + k);

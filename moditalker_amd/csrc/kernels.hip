@@ -85,6 +85,7 @@ hipError_t launch_gn_stats(const StatsArgs& a, hipStream_t s) {
 // ResBlock(down=True) input path: avgpool2x2(SiLU(GN(x))) and avgpool2x2(x)
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_pool_down(const PoolArgs a) {
+    touch_kernargs<(int)sizeof(PoolArgs)>();
     // grid (blocks over dst tokens x channel quads, B): one batch element per block row, so the group
     // statistics (summed over the privatised copies) are finalised once per block into LDS
     __shared__ float2 s_mr[3][32];
@@ -174,6 +175,7 @@ __device__ __forceinline__ float lane_swap_max32(float x) {
 
 template <int D, int QW, int KSP>
 __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
+    touch_kernargs<(int)sizeof(AttnArgs)>();
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr int VW = D >= 16 ? 4 : D / 4;        // floats per q/k fragment
     constexpr int NV = D >= 16 ? D / 16 : 1;       // fragments per row
@@ -418,6 +420,7 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
 // =====================================================================================
 // out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]   (unet.py:700-705,148-154,193); one wave per n.
 __global__ __launch_bounds__(256) void k_linear(const LinearArgs a) {
+    touch_kernargs<(int)sizeof(LinearArgs)>();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
     const int b = blockIdx.y;

@@ -69,8 +69,47 @@ struct ConvArgs {
     int* tickets;            // [B * row tiles * column tiles] arrival counters (zero between launches)
     float* slab;             // [KS][B][Lout][N]
     int xmap;                // ConvTile::XM
+    // Gather by arithmetic instead of by table (same values -- mtv_create() checks the formula against the
+    // tables on the host and leaves these 0 if they ever disagreed): the kernel then needs no global load
+    // before its operand loads.  geo_main: 0 = `gather` table / identity, 1 = 3x3 taps on the output grid,
+    // 2 = 3x3 taps on the nearest-x2-upsampled source.  geo_skip: 0 = `gather_skip` table / identity,
+    // 2 = nearest-x2-upsampled source.  (geo_r, geo_t) = output-level plane geometry.
+    int geo_main, geo_skip, geo_r, geo_t;
     unsigned long long* dbg; // phase timestamps for tools/ubench/conv_bench (nullptr in the product)
 };
+
+// Touch every 64-byte line of the kernel-argument block at kernel entry.  The compiler otherwise loads
+// struct fields lazily, each first touch of a line being a scalar-cache miss that goes all the way to
+// memory (~1 us) and they serialise (load, wait, compute, load the next line, wait ...): three to four
+// dependent misses at the head of every launch.  One combined wait here, then every later s_load hits.
+#if defined(__HIPCC__)
+template <int BYTES>
+__device__ __forceinline__ void touch_kernargs() {
+    typedef const __attribute__((address_space(4))) unsigned* kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned x = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) x ^= ka[o / 4];
+    x ^= ka[(BYTES - 4) / 4];                  // (the block need not start on a line boundary)
+    asm volatile("" ::"s"(x));
+}
+#endif
+
+// Source token of (tap ky,kx in 0..2; output token) on the tri-plane grid of a level with planes
+// xy r x r | yt t x r | xt t x r; `up`: the source lives on the (r/2, t/2) level (nearest x2 upsample).
+// Returns -1 for zero padding, else token | plane << 28 (the layout of the kernel's index table).
+__host__ __device__ inline int geo_source(int r, int t, int tok, int ky, int kx, bool up) {
+    const int b1 = r * r, b2 = b1 + t * r;
+    const int p = tok >= b2 ? 2 : (tok >= b1 ? 1 : 0);
+    const int off = p == 0 ? 0 : (p == 1 ? b1 : b2), h = p == 0 ? r : t;
+    const int local = tok - off, y = local / r, x = local - y * r;
+    const int yy = y + ky - 1, xx = x + kx - 1;
+    if (yy < 0 || yy >= h || xx < 0 || xx >= r) return -1;
+    if (!up) return (off + yy * r + xx) | (p << 28);
+    const int rs = r >> 1, ts = t >> 1, b1s = rs * rs, b2s = b1s + ts * rs;
+    const int offs = p == 0 ? 0 : (p == 1 ? b1s : b2s);
+    return (offs + (yy >> 1) * rs + (xx >> 1)) | (p << 28);
+}
 
 struct StatsArgs {   // (fallback pass: writes copy 0 only)
     const float* src[2];

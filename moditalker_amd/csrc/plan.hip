@@ -113,6 +113,7 @@ struct mtv_ctx {
     std::map<std::string, std::pair<int, int>> taps;   // tap name -> (level, C) ; buffer = bufs["tap." + name]
     std::vector<void*> allocs;
     std::vector<int*> g3, gup3, gup1;           // gather tables per level
+    bool geo_ok = true;                         // geo_source() reproduced every table on the host (mtv_create)
     double* stats = nullptr;                     // GN site arena
     size_t stats_bytes = 0;
     size_t stats_copy_doubles = 0;              // doubles per privatised copy of the arena
@@ -395,6 +396,14 @@ struct Builder {
         a0.B = B;
         a0.seg_out = c->lv[lvl_out].seg();
         a0.stat_cstride = (unsigned)c->stats_copy_doubles;
+        static const bool geo_env = []() { const char* e = getenv("MTV_GEO"); return !e || atoi(e) != 0; }();
+        if (c->geo_ok && geo_env) {                 // gather tables -> arithmetic (checked equal in mtv_create)
+            const int lo = lvl_out;
+            a0.geo_r = c->lv[lo].r;
+            a0.geo_t = c->lv[lo].t;
+            if (a0.gather && a0.ntaps == 9) a0.geo_main = a0.gather == c->g3[lo] ? 1 : (a0.gather == c->gup3[lo] ? 2 : 0);
+            if (a0.gather_skip) a0.geo_skip = a0.gather_skip == c->gup1[lo] ? 2 : 0;
+        }
         const int nchunks = a0.ntaps * (a0.Cmain / 16) + a0.Cskip / 16;
         account_conv(a0);
         auto op = std::make_shared<ConvOp>();
@@ -947,14 +956,37 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
             *d = (int*)p;
             return MTV_OK;
         };
+        // the kernels compute these indices arithmetically (geo_source); the tables stay as the reference
+        // the formula is checked against here, and as the fallback if it ever disagreed
+        const Level& lv = c->lv[l];
+        auto same_as_formula = [&](const std::vector<int>& h, int ntaps, bool upm) {
+            for (int t = 0; t < ntaps; ++t)
+                for (int tok = 0; tok < lv.L; ++tok) {
+                    const int g = ntaps == 9 ? geo_source(lv.r, lv.t, tok, t / 3, t % 3, upm) : geo_source(lv.r, lv.t, tok, 1, 1, upm);
+                    const int want = h[(size_t)t * lv.L + tok];
+                    if ((g < 0 ? -1 : (g & 0x0FFFFFFF)) != want) return false;
+                    if (g >= 0 && ntaps == 9) {          // plane bits must equal the source segment of the token
+                        const Level& sl = upm ? c->lv[l + 1] : lv;
+                        const int st = g & 0x0FFFFFFF, pl = st >= sl.b2 ? 2 : (st >= sl.b1 ? 1 : 0);
+                        if ((g >> 28) != pl) return false;
+                    }
+                }
+            return true;
+        };
         int* d = nullptr;
-        if ((rc = up(make_gather3(c->lv[l], c->lv[l], false), &d)) != MTV_OK) return rc;
+        {
+            const std::vector<int> h = make_gather3(lv, lv, false);
+            c->geo_ok = c->geo_ok && same_as_formula(h, 9, false);
+            if ((rc = up(h, &d)) != MTV_OK) return rc;
+        }
         c->g3.push_back(d);
         d = nullptr;
         int* d1 = nullptr;
         if (l + 1 < cfg->n_levels) {
-            if ((rc = up(make_gather3(c->lv[l], c->lv[l + 1], true), &d)) != MTV_OK) return rc;
-            if ((rc = up(make_gather_up1(c->lv[l], c->lv[l + 1]), &d1)) != MTV_OK) return rc;
+            const std::vector<int> h3 = make_gather3(lv, c->lv[l + 1], true), h1 = make_gather_up1(lv, c->lv[l + 1]);
+            c->geo_ok = c->geo_ok && same_as_formula(h3, 9, true) && same_as_formula(h1, 1, true);
+            if ((rc = up(h3, &d)) != MTV_OK) return rc;
+            if ((rc = up(h1, &d1)) != MTV_OK) return rc;
         }
         c->gup3.push_back(d);
         c->gup1.push_back(d1);
