@@ -33,6 +33,7 @@ namespace mtv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     touch_kernargs<(int)sizeof(ConvArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float2 s_mr[3][32];
+    __shared__ f64x2 s_dp[96];                 // (sum, sum of squares) per (plane, group), copies added up
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // SGPR: the K walk is scalar
     const int i = lane & 15, q = lane >> 4;
@@ -378,29 +380,44 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             }
         };
         if (tid * PER < Cmain) fetch(tid * PER);
+        // (plane, group) sums over the privatised copies: 8 independent 16-byte loads per thread, all in flight
+        // together.  A cross-plane site (AttentionBlock1D) adds its three planes up through LDS afterwards --
+        // summing 24 entries per thread in registers made the compiler serialise the loads.
+        const bool whole = a.gn.whole != 0;
+        f64x2 v0 = {0.0, 0.0};
+        if (tid < 96) {
+#pragma unroll
+            for (int k = 0; k < STAT_COPIES; ++k)
+                v0 += *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)tid * 2);
+        }
+        if constexpr (NTH < 96) {                       // one-wave workgroups: entries 64..95 in a second round
+            if (tid < 32) {
+                f64x2 v1 = {0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < STAT_COPIES; ++k)
+                    v1 += *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)(64 + tid) * 2);
+                s_dp[64 + tid] = v1;
+            }
+            if (tid < 64) s_dp[tid] = v0;
+            __syncthreads();
+        } else if (whole) {
+            if (tid < 96) s_dp[tid] = v0;
+            __syncthreads();
+        }
         for (int e = tid; e < 96; e += NTH) {
             const int sg = e >> 5, g = e & 31;
-            double s = 0.0, ss = 0.0, n;
-            if (a.gn.whole) {
-#pragma unroll
-                for (int k = 0; k < STAT_COPIES; ++k) {
-                    const double* S = a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192;
-                    s += S[g * 2] + S[64 + g * 2] + S[128 + g * 2];
-                    ss += S[g * 2 + 1] + S[64 + g * 2 + 1] + S[128 + g * 2 + 1];
-                }
+            f64x2 v;
+            double n;
+            if (whole) {
+                v = (s_dp[g] + s_dp[32 + g]) + s_dp[64 + g];
                 n = (double)a.seg_src.L * a.gn.gs;
             } else {
-#pragma unroll
-                for (int k = 0; k < STAT_COPIES; ++k) {
-                    const double* S = a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192;
-                    s += S[sg * 64 + g * 2];
-                    ss += S[sg * 64 + g * 2 + 1];
-                }
+                v = NTH < 96 ? s_dp[e] : v0;
                 const int len = sg == 0 ? a.seg_src.b1 : (sg == 1 ? a.seg_src.b2 - a.seg_src.b1 : a.seg_src.L - a.seg_src.b2);
                 n = (double)len * a.gn.gs;
             }
-            const double mean = s / n;
-            double var = ss / n - mean * mean;
+            const double mean = v[0] / n;
+            double var = v[1] / n - mean * mean;
             var = var < 0.0 ? 0.0 : var;
             s_mr[sg][g] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));   // fp64 only where cancellation bites
         }
