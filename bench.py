@@ -81,8 +81,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # (MTV_BENCH_FORCE_DIST=1: go through the RCCL path with a single rank too -- a self-test of the N>1 code)
+    use_dist = world > 1 or os.environ.get("MTV_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     R, T, S = args.res, 16, 250
@@ -113,7 +116,7 @@ def main():
                    "mtv_ddim_sample")
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -123,13 +126,13 @@ def main():
     xt = x.clone()
     t0 = time.perf_counter()
     run(K, xt)
-    if world > 1:                                 # final gather of the finished latents (32 KiB each)
+    if use_dist:                                  # final gather of the finished latents (32 KiB each)
         out = [torch.empty_like(xt) for _ in range(world)]
         dist.all_gather(out, xt)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     assert torch.isfinite(xt).all()
@@ -302,7 +305,7 @@ def main():
     barrier()
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
