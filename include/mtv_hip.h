@@ -131,6 +131,17 @@ int mtv_profile_forward(mtv_ctx* ctx, int batch, int iters, mtv_op_time* out, in
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
 int mtv_set_eager(mtv_ctx* ctx, int eager);
 
+/* Host-only self-test (needs no device): the conv kernels compute their 3x3 / nearest-upsample gather
+ * indices arithmetically on the tri-plane grid (planes xy R x R | yt T x R | xt T x R per level, i.e.
+ * the slicing of unet.py:1039-1053 and the Upsample/conv padding of unet.py:531-598); this checks that
+ * arithmetic against explicitly constructed index tables for every level of a (res, frames, n_levels)
+ * geometry.  Returns 0 when all agree, else 1 + the first level that does not (<0: bad arguments). */
+int mtv_selftest_geometry(int res, int frames, int n_levels);
+/* The arithmetic itself, for tests: source token of tap (ky, kx in 0..2) at output token `tok` of a level with
+ * planes res x res | frames x res | frames x res; up != 0: the source is the (res/2, frames/2) level under a
+ * nearest x2 upsample.  Returns -1 for zero padding, else source_token | plane << 28. */
+int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,8 @@ SYMBOLS = [
     ("mtv_get_work", C.c_int, [_P, C.POINTER(MtvWork)]),
     ("mtv_set_eager", C.c_int, [_P, C.c_int]),
     ("mtv_profile_forward", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(MtvOpTime), C.c_int, C.POINTER(C.c_int), _P]),
+    ("mtv_selftest_geometry", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("mtv_debug_gather_index", C.c_int, [C.c_int] * 6),
 ]
 
 _lib: Optional[C.CDLL] = None

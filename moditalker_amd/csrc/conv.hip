@@ -18,12 +18,13 @@
 //   B: lane (j,q) loads W[c0 + 4q + s][n0 + NT*j .. +NT-1] for s = 0..3; column block nb of the
 //      wave tile is output channel n0 + NT*j + nb.
 //
-// Work split: grid.x = B * ceil(Lout / 16MT) row tiles (a tile never straddles a batch element),
-// grid.y = N / 16NT column tiles, grid.z = KS cross-workgroup K slices; the NW waves of a
-// workgroup split their K range further.  K = (tap, 16-channel chunk) pairs; each wave walks its
-// chunk range with a two-deep register pipeline (loads of chunk i+1 in flight under the MFMAs of
-// chunk i).  Waves are summed in LDS in fixed order (deterministic); with KS > 1 the partial tiles go
-// to a slab and the slice that finishes last adds them in fixed order inside the same launch.
+// Work split: a 1-D grid of B * ceil(Lout / 16MT) row tiles (a tile never straddles a batch element)
+// x N / 16NT column tiles x KS cross-workgroup K slices, decoded from blockIdx.x in an XCD-aware
+// order (ConvArgs::xmap); the NW waves of a workgroup split their K range further.  K = (tap,
+// 16-channel chunk) pairs; each wave walks its chunk range with a ring of DEPTH (2-4) chunks in
+// flight (loads of chunks i+1.. under the MFMAs of chunk i).  Waves are summed in LDS in fixed order
+// (deterministic); with KS > 1 the partial tiles go to a slab and the slice that finishes last adds
+// them in fixed order inside the same launch.
 #include <cstdio>
 #include <cstdlib>
 
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
 
     if constexpr (MTV_ABLATE & 16) return;   // prologue only
     MTV_STAMP(2);
-    // ---- K loop over this wave's chunk range, two-deep register pipeline
+    // ---- K loop over this wave's chunk range: a ring of DEPTH chunks in flight
     const bool act = a.gn.act != 0;
 
     f32x4 acc[MT][NT];

@@ -334,6 +334,36 @@ static std::vector<int> make_gather_up1(const Level& dst, const Level& src) {
     return g;
 }
 
+static std::vector<Level> make_levels(int res, int frames, int n_levels) {
+    std::vector<Level> lv;
+    for (int l = 0; l < n_levels; ++l) {
+        Level v;
+        v.r = res >> l;
+        v.t = frames >> l;
+        v.b1 = v.r * v.r;
+        v.b2 = v.b1 + v.t * v.r;
+        v.L = v.b2 + v.t * v.r;
+        lv.push_back(v);
+    }
+    return lv;
+}
+
+// Does geo_source() (what the kernels evaluate) reproduce a gather table (the straightforward construction
+// above)?  `src` = the level the table reads from (the next level for the upsampling tables).
+static bool table_matches_formula(const std::vector<int>& h, int ntaps, bool upm, const Level& lv, const Level& src) {
+    for (int t = 0; t < ntaps; ++t)
+        for (int tok = 0; tok < lv.L; ++tok) {
+            const int g = ntaps == 9 ? geo_source(lv.r, lv.t, tok, t / 3, t % 3, upm) : geo_source(lv.r, lv.t, tok, 1, 1, upm);
+            const int want = h[(size_t)t * lv.L + tok];
+            if ((g < 0 ? -1 : (g & 0x0FFFFFFF)) != want) return false;
+            if (g >= 0) {                            // plane bits must equal the source segment of the token
+                const int st = g & 0x0FFFFFFF, pl = st >= src.b2 ? 2 : (st >= src.b1 ? 1 : 0);
+                if ((g >> 28) != pl) return false;
+            }
+        }
+    return true;
+}
+
 // =====================================================================================
 // plan builder
 // =====================================================================================
@@ -935,15 +965,7 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
     c->cfg = *cfg;
     HIPCHK(hipGetDevice(&c->device));
     c->emb_dim = 4 * cfg->model_channels;
-    for (int l = 0; l < cfg->n_levels; ++l) {
-        Level v;
-        v.r = cfg->res >> l;
-        v.t = cfg->frames >> l;
-        v.b1 = v.r * v.r;
-        v.b2 = v.b1 + v.t * v.r;
-        v.L = v.b2 + v.t * v.r;
-        c->lv.push_back(v);
-    }
+    c->lv = make_levels(cfg->res, cfg->frames, cfg->n_levels);
     int rc = build_structure(c.get());
     if (rc != MTV_OK) return rc;
     // gather tables
@@ -959,24 +981,10 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
         // the kernels compute these indices arithmetically (geo_source); the tables stay as the reference
         // the formula is checked against here, and as the fallback if it ever disagreed
         const Level& lv = c->lv[l];
-        auto same_as_formula = [&](const std::vector<int>& h, int ntaps, bool upm) {
-            for (int t = 0; t < ntaps; ++t)
-                for (int tok = 0; tok < lv.L; ++tok) {
-                    const int g = ntaps == 9 ? geo_source(lv.r, lv.t, tok, t / 3, t % 3, upm) : geo_source(lv.r, lv.t, tok, 1, 1, upm);
-                    const int want = h[(size_t)t * lv.L + tok];
-                    if ((g < 0 ? -1 : (g & 0x0FFFFFFF)) != want) return false;
-                    if (g >= 0 && ntaps == 9) {          // plane bits must equal the source segment of the token
-                        const Level& sl = upm ? c->lv[l + 1] : lv;
-                        const int st = g & 0x0FFFFFFF, pl = st >= sl.b2 ? 2 : (st >= sl.b1 ? 1 : 0);
-                        if ((g >> 28) != pl) return false;
-                    }
-                }
-            return true;
-        };
         int* d = nullptr;
         {
             const std::vector<int> h = make_gather3(lv, lv, false);
-            c->geo_ok = c->geo_ok && same_as_formula(h, 9, false);
+            c->geo_ok = c->geo_ok && table_matches_formula(h, 9, false, lv, lv);
             if ((rc = up(h, &d)) != MTV_OK) return rc;
         }
         c->g3.push_back(d);
@@ -984,7 +992,7 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
         int* d1 = nullptr;
         if (l + 1 < cfg->n_levels) {
             const std::vector<int> h3 = make_gather3(lv, c->lv[l + 1], true), h1 = make_gather_up1(lv, c->lv[l + 1]);
-            c->geo_ok = c->geo_ok && same_as_formula(h3, 9, true) && same_as_formula(h1, 1, true);
+            c->geo_ok = c->geo_ok && table_matches_formula(h3, 9, true, lv, c->lv[l + 1]) && table_matches_formula(h1, 1, true, lv, c->lv[l + 1]);
             if ((rc = up(h3, &d)) != MTV_OK) return rc;
             if ((rc = up(h1, &d1)) != MTV_OK) return rc;
         }
@@ -1278,6 +1286,26 @@ int mtv_get_work(const mtv_ctx* c, mtv_work* out) {
     if (!c || !out) return fail(MTV_ERR_INVALID, "null argument");
     *out = c->work;
     return MTV_OK;
+}
+
+int mtv_selftest_geometry(int res, int frames, int n_levels) {
+    if (res <= 0 || frames <= 0 || n_levels <= 0 || n_levels > 8 || (res >> (n_levels - 1)) <= 0 || (frames >> (n_levels - 1)) <= 0)
+        return fail(MTV_ERR_INVALID, "selftest_geometry: bad geometry");
+    const std::vector<Level> lv = make_levels(res, frames, n_levels);
+    for (int l = 0; l < n_levels; ++l) {
+        if (!table_matches_formula(make_gather3(lv[l], lv[l], false), 9, false, lv[l], lv[l])) return l + 1;
+        if (l + 1 < n_levels) {
+            if (!table_matches_formula(make_gather3(lv[l], lv[l + 1], true), 9, true, lv[l], lv[l + 1])) return l + 1;
+            if (!table_matches_formula(make_gather_up1(lv[l], lv[l + 1]), 1, true, lv[l], lv[l + 1])) return l + 1;
+        }
+    }
+    return 0;
+}
+
+int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up) {
+    if (res <= 0 || frames <= 0 || tok < 0 || tok >= res * res + 2 * frames * res || ky < 0 || ky > 2 || kx < 0 || kx > 2)
+        return fail(MTV_ERR_INVALID, "debug_gather_index: bad arguments") - 1;   // (-2: distinct from "padding")
+    return geo_source(res, frames, tok, ky, kx, up != 0);
 }
 
 int mtv_set_eager(mtv_ctx* c, int eager) {

@@ -142,6 +142,7 @@ def test_config3_512px_clip_vs_oracle():
     (8, 4, SHALLOW_CFG, 3),                                   # BASELINE config 1 geometry (4-frame 64x64)
     (16, 8, NARROW_CFG, 1),
     (8, 8, dict(SHALLOW_CFG, use_scale_shift_norm=False), 2), # the h + emb_out branch (unet.py:204-206)
+    (24, 8, SHALLOW_CFG, 2),                                  # not powers of two: 60-token deepest level, ragged tiles
 ])
 def test_other_geometries_vs_oracle(R, T, cfg, B):
     from oracle import ref_unet

@@ -128,3 +128,41 @@ def test_filler_is_deterministic_and_well_scaled():
     assert abs(float(a.std()) - (1.0 / (32 * 9)) ** 0.5) < 0.1 * (1.0 / (32 * 9)) ** 0.5
     n = filler.normal("n", (200000,), seed=1)
     assert abs(float(n.mean())) < 0.01 and abs(float(n.std()) - 1.0) < 0.01
+
+
+@pytest.mark.parametrize("R,T,levels", [(32, 16, 4), (64, 16, 4), (8, 4, 3), (24, 8, 3), (12, 6, 2)])
+def test_arithmetic_gather_matches_torch_unfold_semantics(R, T, levels):
+    """The conv kernels compute their im2col source indices arithmetically (csrc/mtv_internal.h: geo_source).
+    Pin that arithmetic, through the C ABI and without a device, to what torch's own ops do to an index image:
+    F.pad(-1) + F.unfold(3x3) = the zero-padded conv2d of unet.py:131-167 on each plane; F.interpolate(x2,
+    nearest) in front of it = Upsample (unet.py:531-561) inside a ResBlock(up=True)."""
+    import torch.nn.functional as F
+    from moditalker_amd import _lib
+    lib = _lib.load()
+    assert lib.mtv_selftest_geometry(R, T, levels) == 0
+    for lvl in range(levels):
+        r, t = R >> lvl, T >> lvl
+        planes = [(r, r, 0), (t, r, r * r), (t, r, r * r + t * r)]           # (h, w, first token) of xy | yt | xt
+        for up in (0, 1):
+            if up and lvl + 1 >= levels:
+                continue
+            rs, ts = (r >> 1, t >> 1) if up else (r, t)
+            src_planes = [(rs, rs, 0), (ts, rs, rs * rs), (ts, rs, rs * rs + ts * rs)]
+            for p, ((h, w, off), (hs, ws, offs)) in enumerate(zip(planes, src_planes)):
+                img = (torch.arange(hs * ws, dtype=torch.float32) + offs).reshape(1, 1, hs, ws)
+                if up:
+                    img = F.interpolate(img, scale_factor=2, mode="nearest")
+                assert img.shape[-2:] == (h, w)
+                cols = F.unfold(F.pad(img, (1, 1, 1, 1), value=-1.0), kernel_size=3)[0].to(torch.int64)   # [9, h*w]
+                # sample the plane densely when small, on a stride when large (borders always included)
+                toks = range(h * w) if h * w <= 1024 else sorted(set(list(range(0, h * w, 7)) + list(range(w)) + list(range(h * w - w, h * w))
+                                                                     + [y * w for y in range(h)] + [y * w + w - 1 for y in range(h)]))
+                for local in toks:
+                    for tap in range(9):
+                        got = lib.mtv_debug_gather_index(r, t, off + local, tap // 3, tap % 3, up)
+                        want = int(cols[tap, local])
+                        if want < 0:
+                            assert got == -1, (lvl, up, p, local, tap)
+                        else:
+                            assert got >= 0 and (got & 0x0FFFFFFF) == want and (got >> 28) == p, (lvl, up, p, local, tap, got, want)
+    assert lib.mtv_debug_gather_index(R, T, R * R + 2 * T * R, 1, 1, 0) == -2      # out of range -> error, not "padding"
