@@ -85,13 +85,28 @@ struct ConvArgs {
 #if defined(__HIPCC__)
 template <int BYTES>
 __device__ __forceinline__ void touch_kernargs() {
-    typedef const __attribute__((address_space(4))) unsigned* kptr;
+    static_assert(BYTES <= 8 * 64, "argument block larger than 8 lines");
+    typedef const __attribute__((address_space(4))) void* kptr;
     kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned x = 0;
-#pragma unroll
-    for (int o = 0; o < BYTES; o += 64) x ^= ka[o / 4];
-    x ^= ka[(BYTES - 4) / 4];                  // (the block need not start on a line boundary)
-    asm volatile("" ::"s"(x));
+    // written out in assembly so that the loads stay together, first, with ONE wait (left to the scheduler they
+    // get interleaved with the first real argument loads and the misses serialise again)
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7;
+    constexpr int LAST = BYTES - 4;              // (the block need not start on a line boundary)
+    asm volatile(
+        "s_load_dword %0, %8, 0x0\n\t"
+        "s_load_dword %1, %8, %9\n\t"
+        "s_load_dword %2, %8, %10\n\t"
+        "s_load_dword %3, %8, %11\n\t"
+        "s_load_dword %4, %8, %12\n\t"
+        "s_load_dword %5, %8, %13\n\t"
+        "s_load_dword %6, %8, %14\n\t"
+        "s_load_dword %7, %8, %15\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+        : "s"(ka), "n"(BYTES > 64 ? 64 : LAST), "n"(BYTES > 128 ? 128 : LAST), "n"(BYTES > 192 ? 192 : LAST),
+          "n"(BYTES > 256 ? 256 : LAST), "n"(BYTES > 320 ? 320 : LAST), "n"(BYTES > 384 ? 384 : LAST), "n"(LAST)
+        : "memory");
+    __builtin_amdgcn_sched_barrier(0);           // nothing (in particular no argument load) is scheduled above this
 }
 #endif
 
