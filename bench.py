@@ -278,7 +278,7 @@ def main():
                          peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches_per_step=attn["launches"], flops_per_step=attn["flops"])
         attn_roof["frac"] = round(attn_roof["achieved"] / MFMA_F32_PEAK_TF, 4)
         result = {
-            "metric": "denoise-steps/sec (16-frame 256^2 clip, 250 DDIM steps)",
+            "metric": f"denoise-steps/sec (16-frame {8 * R}^2 clip, 250 DDIM steps)",
             "value": round(world * K / dt, 3),
             "unit": "denoise-steps/s",
             "n_gpus": world,
