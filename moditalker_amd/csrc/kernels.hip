@@ -200,11 +200,16 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     const int j = lane & 15, g = lane >> 4;
     const int qw = wave % QW, kh = wave / QW;      // query tile of the workgroup, key part of each block
     // which (segment, 64-query block)
+    // 1-D grid, head fastest: consecutive workgroup ids go round-robin over the 8 XCDs, so with H = 8 every
+    // workgroup of a head runs on the same XCD and the head's K/V rows are fetched into ONE L2 (speed only).
+    const int h = blockIdx.x % a.H;
+    const int rest = blockIdx.x / a.H;
+    const int nblk = a.blk_prefix[a.nseg];
+    const int qblk = rest % nblk, b = rest / nblk;
     int sg = 0;
-    while (sg + 1 < a.nseg && (int)blockIdx.x >= a.blk_prefix[sg + 1]) ++sg;
-    const int q0 = (blockIdx.x - a.blk_prefix[sg]) * (16 * QW) + qw * 16;
+    while (sg + 1 < a.nseg && qblk >= a.blk_prefix[sg + 1]) ++sg;
+    const int q0 = (qblk - a.blk_prefix[sg]) * (16 * QW) + qw * 16;
     const int start = a.seg_start[sg], len = a.seg_len[sg];
-    const int h = blockIdx.y, b = blockIdx.z;
     const int RS = 3 * a.C;
     const float* base = a.qkv + (size_t)b * a.L * RS + (size_t)h * 3 * D;
     const float scale = a.scale;
@@ -392,7 +397,7 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     const int qw = wide ? 4 : 1;
     a.blk_prefix[0] = 0;
     for (int i = 0; i < a.nseg; ++i) a.blk_prefix[i + 1] = a.blk_prefix[i] + (a.seg_len[i] + 16 * qw - 1) / (16 * qw);
-    dim3 grid(a.blk_prefix[a.nseg], a.H, a.B);
+    dim3 grid((unsigned)(a.blk_prefix[a.nseg] * a.H * a.B));
     static int wide_ksp = -1;                       // tuning aid: MTV_ATT_KSP=2|4 (key parts of the 4-tile shape)
     if (wide_ksp < 0) {
         wide_ksp = 2;   // 4 (1024-thread workgroups) measured equal in time; 2 keeps workgroups at 512 threads
