@@ -863,6 +863,18 @@ static int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
         snprintf(key, sizeof key, "B%d L%d/%d/%d N%d t%d C%d+%d gn%d f%d r%d s%d cm%d", a.B, a.Lout, a.Lsrc, a.Lskip, a.N, a.ntaps, a.Cmain, a.Cskip,
                  a.gn.sums ? 1 : 0, a.gn.film ? 1 : 0, a.res ? 1 : 0, a.nstat, a.out_cm);
         auto it = c->tune_cache.find(key);
+        if (it != c->tune_cache.end()) {             // an entry read from MTV_TUNE_CACHE is only trusted if it is launchable
+            const ConvTile& t = it->second;
+            const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
+            const bool shape_ok = (t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
+                                  (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
+                                  t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1);
+            if (!shape_ok || t.NW * t.KS > nchunks || (t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
+                conv_smem_bytes(a, t) > 120 * 1024) {
+                c->tune_cache.erase(it);
+                it = c->tune_cache.end();
+            }
+        }
         if (it == c->tune_cache.end()) {
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
             const double wbytes = 4.0 * ((double)a.ntaps * a.Cmain + a.Cskip) * a.N;
