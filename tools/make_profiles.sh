@@ -1,0 +1,36 @@
+#!/bin/bash
+# Regenerates every file under profiles/ for round NN on a box with one MI355X (run from the repo root, e.g.
+#   gpurun --timeout 900 -- 'bash tools/make_profiles.sh 01').
+# Outputs go to gpurun_out/final/; copy them into profiles/ as the README there names them.
+set -x
+NN=${1:-01}
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp MTV_TUNE_CACHE=/tmp/mtv_tune_profiles.txt
+O=gpurun_out/final; rm -rf $O; mkdir -p $O
+# 1. un-profiled run: auto-tunes every conv shape once and persists the choice, so the profiled processes below
+#    contain only the sampling loop
+timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --batched-clips 0 > /dev/null 2>&1
+# 2. per-launch hipEvent table (op names / shapes / tiles; also the join key for per_op_rocprof.py)
+timeout 120 python tools/profile_ops.py --iters 20 > $O/r${NN}_per_launch_hipevents.txt 2>$O/ops.err
+# 3. the bench line (N=1, with cpu_baseline and batched_info)
+timeout 400 python bench.py --steps 250 --warmup 25 > $O/r${NN}_bench_n1.json 2>$O/bench.err
+# 4. kernel trace + stats of the same command
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- \
+    python bench.py --steps 100 --warmup 10 --no-cpu-baseline --batched-clips 0 > $O/kt.log 2>&1
+KT=$(find $O/kt -name '*kernel_trace.csv' | head -1)
+cp "$(find $O/kt -name '*kernel_stats.csv' | head -1)" $O/r${NN}_rocprofv3_kernel_stats.csv
+python tools/per_op_rocprof.py $O/r${NN}_per_launch_hipevents.txt $KT $O/r${NN}_per_op_rocprof.txt > /dev/null 2>&1
+# 5. PMC passes, each in its own run, kernel trace only (never combined with hip/hsa/sys trace domains)
+for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- \
+        python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 > $O/pmc_$c.log 2>&1
+    echo "pmc $c rc=$?"
+done
+PF=$(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+PW=$(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+python tools/summarize_profile.py $KT ${PF:+--fetch $PF} ${PW:+--write $PW} > $O/r${NN}_step_summary.txt 2>&1
+# 6. configs[3] (R=64), informational
+timeout 300 python bench.py --res 64 --steps 40 --warmup 10 --no-cpu-baseline --batched-clips 0 > /dev/null 2>&1
+timeout 300 python bench.py --res 64 --steps 150 --warmup 15 --no-cpu-baseline --batched-clips 0 > $O/r${NN}_bench_res64_n1.json 2>/dev/null
+rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+tail -25 $O/r${NN}_step_summary.txt
