@@ -22,21 +22,47 @@ def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, n_items, world_size))
 
 
-def sample_clips_sharded(sample_fn: Callable[[int], torch.Tensor], n_clips: int,
-                         group: Optional[dist.ProcessGroup] = None) -> List[torch.Tensor]:
+def _run_local(sample_fn, mine: Sequence[int], clips_per_call: int) -> List[torch.Tensor]:
+    """This rank's clips, one call each -- or `clips_per_call` clips per call: sample_fn then receives a list
+    of clip indices and returns [k,C,L] (one DDPM.sample(batch_size=k): several clips batched on the GPU
+    amortise the per-launch floor and the weight stream, 2.4x the clip throughput at k=8)."""
+    if clips_per_call < 1:
+        raise ValueError("clips_per_call must be >= 1")
+    if clips_per_call == 1:
+        outs = [sample_fn(i) for i in mine]
+        for i, o in zip(mine, outs):
+            if o.shape[0] != 1:
+                raise ValueError(f"sample_fn({i}) must return [1,C,L], got {tuple(o.shape)}")
+        return outs
+    outs: List[torch.Tensor] = []
+    for k0 in range(0, len(mine), clips_per_call):
+        idx = list(mine[k0:k0 + clips_per_call])
+        o = sample_fn(idx)
+        if o.shape[0] != len(idx):
+            raise ValueError(f"sample_fn({idx}) must return [{len(idx)},C,L], got {tuple(o.shape)}")
+        outs.extend(o[j:j + 1] for j in range(len(idx)))
+    return outs
+
+
+def sample_clips_sharded(sample_fn: Callable[..., torch.Tensor], n_clips: int,
+                         group: Optional[dist.ProcessGroup] = None, clips_per_call: int = 1) -> List[torch.Tensor]:
     """Run `sample_fn(clip_index) -> [1,C,L]` for this rank's clips and all_gather the results.
 
-    Returns the list of all n_clips results in clip order on every rank.  Works on any backend
+    With clips_per_call = k > 1 the rank's clips are sampled k at a time: `sample_fn([i0, i1, ...]) -> [k,C,L]`
+    (the reference's sample.py:377-384 call with batch_size=k; per-clip noise keeps every clip's result
+    independent of the grouping).
+
+    Returns the list of all n_clips results ([1,C,L] each) in clip order on every rank.  Works on any backend
     (`nccl` = RCCL on the GPU box, `gloo` in the CPU tests); without an initialised process group it
     degenerates to a plain loop."""
     if not (dist.is_available() and dist.is_initialized()):
-        return [sample_fn(i) for i in range(n_clips)]
+        return _run_local(sample_fn, list(range(n_clips)), clips_per_call)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine = shard_indices(n_clips, rank, world)
     if n_clips < world:
         raise ValueError(f"sample_clips_sharded needs n_clips >= world_size ({n_clips} < {world})")
     per_rank = (n_clips + world - 1) // world
-    outs = [sample_fn(i) for i in mine]
+    outs = _run_local(sample_fn, mine, clips_per_call)
     ref = outs[0]
     slab = torch.zeros((per_rank,) + tuple(ref.shape), dtype=ref.dtype, device=ref.device)
     for k, o in enumerate(outs):

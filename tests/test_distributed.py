@@ -66,3 +66,50 @@ def test_shard_indices():
     assert shard_indices(10, 1, 4) == [1, 5, 9]
     with pytest.raises(ValueError):
         shard_indices(4, 4, 4)
+
+
+def _fake_batched(idx):
+    return torch.cat([_fake_sample(i) for i in idx], dim=0)
+
+
+def _worker_batched(rank, world, port, n_clips, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def fn(idx):
+            calls.append(list(idx))
+            return _fake_batched(idx)
+
+        out = sample_clips_sharded(fn, n_clips, clips_per_call=k)
+        ok = len(out) == n_clips and all(torch.equal(out[i], _fake_sample(i)) for i in range(n_clips))
+        q.put((rank, ok, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sampling_with_clips_batched_per_call_gloo_world2():
+    """B > 1 clips per GPU call: same results, each rank's clips grouped k at a time."""
+    n_clips, k = 7, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_batched, args=(r, 2, port, n_clips, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == [[0, 2, 4], [6]] and res[1][2] == [[1, 3, 5]]
+
+
+def test_batched_per_call_without_process_group_and_shape_check():
+    out = sample_clips_sharded(_fake_batched, 5, clips_per_call=2)
+    assert len(out) == 5 and all(torch.equal(out[i], _fake_sample(i)) for i in range(5))
+    with pytest.raises(ValueError):
+        sample_clips_sharded(lambda idx: _fake_batched(idx)[:1], 4, clips_per_call=2)
+    with pytest.raises(ValueError):
+        sample_clips_sharded(_fake_batched, 4, clips_per_call=0)
