@@ -101,7 +101,7 @@ def main():
     cond = torch.rand(1, 8, L, generator=g, device=dev) * 2 - 1
     image_cond = torch.rand(1, 4, R * R, generator=g, device=dev) * 2 - 1
     x = torch.randn(1, 4, L, generator=g, device=dev)
-    n_noise = max(K, W)
+    n_noise = max(K, W, 1)
     noise = torch.randn(n_noise, 1, 4, L, generator=g, device=dev)
     if os.environ.get("MTV_EAGER") == "1":
         um.set_eager(True)                       # plain launches instead of hipGraph replay
@@ -121,7 +121,8 @@ def main():
         torch.cuda.synchronize(dev)
 
     xw = x.clone()
-    run(W, xw)                                    # warm-up: builds the plan, captures the graph
+    run(max(W, 1), xw)                            # warm-up: builds the plan, auto-tunes, captures the graph
+                                                  # (at least one step even for --warmup 0: set-up is not a step)
     barrier()
     xt = x.clone()
     t0 = time.perf_counter()
