@@ -29,21 +29,11 @@ from .unet import DiffusionWrapper, UNetModel
 
 
 def make_beta_schedule(schedule: str, n_timestep: int, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3) -> np.ndarray:
-    # ddpm.py:77-99; only the schedules the reference can select
-    if schedule == "linear":
-        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
-    elif schedule == "sqrt_linear":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
-    elif schedule == "sqrt":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
-    elif schedule == "cosine":
-        ts = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
-        alphas = torch.cos(ts / (1 + cosine_s) * np.pi / 2).pow(2)
-        alphas = alphas / alphas[0]
-        betas = (1 - alphas[1:] / alphas[:-1]).clamp(0, 0.999)
-    else:
-        raise ValueError(f"schedule '{schedule}' unknown.")
-    return betas.numpy()
+    # ddpm.py:77-99.  The sampling path only ever builds the "linear" schedule (DDPM's default, never overridden by
+    # sample.py:239-245 or the shipped configs); the other names the reference accepts are not part of this path.
+    if schedule != "linear":
+        raise NotImplementedError(f"beta schedule '{schedule}': only 'linear' is reachable from the MToV sampling path")
+    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
 
 
 def ddim_time_pairs(total_timesteps: int, sampling_timesteps: int) -> List[Tuple[int, int]]:
@@ -179,7 +169,10 @@ class DDPM(nn.Module):
             raise TypeError("DDPM.sample drives the HIP denoiser: `model` must be moditalker_amd's "
                             "DiffusionWrapper(UNetModel) (no PyTorch fallback loop)")
         dev = self.betas.device
-        B = x_init.shape[0]
+        # everything below goes down as raw pointers: validate what the reference's torch.cat / broadcasting would
+        B = um.check_inputs(x_init, cond, image_cond)
+        if self.channels != 4 or um.out_channels != 4:
+            raise ValueError("the DDIM loop needs channels == out_channels == 4 (eps has the shape of x)")
         ctx = um.hip_context(dev, B)
         steps, n_draws = ddim_step_table(self.alphas_cumprod, self.sqrt_recip_alphas_cumprod,
                                          self.sqrt_recipm1_alphas_cumprod, pairs, self.ddim_sampling_eta)
@@ -191,6 +184,8 @@ class DDPM(nn.Module):
         noise = noise.to(device=dev, dtype=torch.float32).contiguous()
         if noise.shape[0] < n_draws:
             raise ValueError(f"need {n_draws} in-loop noise draws, got {noise.shape[0]}")
+        if n_draws and tuple(noise.shape[1:]) != tuple(x_init.shape):
+            raise ValueError(f"every noise draw must have the shape of x {tuple(x_init.shape)}; got {tuple(noise.shape[1:])}")
         x = x_init.to(device=dev, dtype=torch.float32).contiguous().clone()
         cf = cond.to(device=dev, dtype=torch.float32).contiguous()
         icf = image_cond.to(device=dev, dtype=torch.float32).contiguous()
@@ -232,7 +227,9 @@ class DDPM(nn.Module):
                noised_start=None, first_stage_model=None, ratio_=None, fix_noise=False, noise=None):
         """ddpm.py:456-484.  Returns [batch_size, channels, L] fp32 on the module's device.
         `noise` (appended kwarg): explicit list/tensor of N(0,1) draws in the reference's draw order
-        (initial x_T or q_sample noise first, then one per non-final step)."""
+        (initial x_T or q_sample noise first, then one per non-final step).
+        `return_intermediates` / `first_stage_model`: accepted and unused, exactly like the reference's DDIM branch
+        (ddpm.py:473-482 forwards return_intermediates only to the unreachable p_sample_loop)."""
         shape = (batch_size, self.channels, self.image_size)
         if not self.is_ddim_sampling:
             raise NotImplementedError("ancestral p_sample_loop is unreachable in the reference's sampling scripts "

@@ -59,12 +59,22 @@ def sample_clips_sharded(sample_fn: Callable[..., torch.Tensor], n_clips: int,
         return _run_local(sample_fn, list(range(n_clips)), clips_per_call)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mine = shard_indices(n_clips, rank, world)
-    if n_clips < world:
-        raise ValueError(f"sample_clips_sharded needs n_clips >= world_size ({n_clips} < {world})")
+    if n_clips < 1:
+        return []
     per_rank = (n_clips + world - 1) // world
     outs = _run_local(sample_fn, mine, clips_per_call)
-    ref = outs[0]
-    slab = torch.zeros((per_rank,) + tuple(ref.shape), dtype=ref.dtype, device=ref.device)
+    # fewer clips than ranks: the surplus ranks idle through the loop and only take part in the gather.  They
+    # learn the result shape/dtype from the group's rank 0 (which always owns clip 0): one tiny object broadcast,
+    # outside the loop.
+    meta = [(tuple(outs[0].shape), outs[0].dtype)] if outs else [None]
+    if n_clips < world:
+        dist.broadcast_object_list(meta, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+    shape, dtype = meta[0]
+    if outs:
+        device = outs[0].device
+    else:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    slab = torch.zeros((per_rank,) + shape, dtype=dtype, device=device)
     for k, o in enumerate(outs):
         slab[k].copy_(o)
     gathered = [torch.empty_like(slab) for _ in range(world)]

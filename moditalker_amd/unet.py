@@ -171,8 +171,8 @@ class UNetModel(nn.Module):
         return cfg
 
     def _release(self):
-        if self._ctx is not None:
-            _lib.load().mtv_destroy(self._ctx)
+        if getattr(self, "_ctx", None) is not None:
+            _lib.load().mtv_destroy(self._ctx)       # (binds the context's own device before freeing)
             self._ctx = None
 
     def __del__(self):
@@ -182,7 +182,39 @@ class UNetModel(nn.Module):
             pass
 
     def _weights_fingerprint(self):
+        """(storage, version) of every parameter.  In-place writes through `.data` (p.data.copy_/lerp_: the usual
+        EMA / weight-surgery idiom) do NOT bump `_version`: call `invalidate_weights()` after such writes.
+        `load_state_dict` and `.to()/_apply` invalidate by themselves."""
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def invalidate_weights(self):
+        """Force a re-upload of all weights to the HIP context before the next forward / sample."""
+        self._fingerprint = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_weights()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._fingerprint = None
+        return r
+
+    # the library handle is process- and device-local: copies / pickles start without one and create their own
+    # lazily (the reference workflow deep-copies the model for its EMA twin, sample.py:226)
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_ctx"], st["_ctx_device"], st["_ctx_batch"], st["_fingerprint"] = None, None, 0, None
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def hip_context(self, device: torch.device, batch: int) -> C.c_void_p:
         """Create (or reuse) the library context for `device`, sized for `batch`, with current weights."""
@@ -253,6 +285,20 @@ class UNetModel(nn.Module):
         return [dict(name=t.name.decode(), ms=float(t.ms), flops=float(t.flops), bytes=float(t.bytes)) for t in table]
 
     # ------------------------------------------------------------------ reference-shaped API
+    def check_inputs(self, x, cond, image_cond) -> int:
+        """Shape contract of the hot path (what `torch.cat` at unet.py:1022-1025 enforces in the reference): the C
+        side only sees raw pointers, so everything that reaches it is validated here.  Returns B."""
+        R, T = self.image_size, self.frames
+        L = R * R + 2 * T * R
+        if x is None or x.dim() != 3 or x.shape[1] != 4 or x.shape[2] != L:
+            raise ValueError(f"x must be [B,4,{L}] for (R,T)=({R},{T}); got {None if x is None else tuple(x.shape)}")
+        B = x.shape[0]
+        if cond is None or tuple(cond.shape) != (B, 8, L):
+            raise ValueError(f"cond must be [{B},8,{L}]; got {None if cond is None else tuple(cond.shape)}")
+        if image_cond is None or image_cond.dim() != 3 or tuple(image_cond.shape[:2]) != (B, 4) or image_cond.shape[2] < R * R:
+            raise ValueError(f"image_cond must be [{B},4,>={R * R}]; got {None if image_cond is None else tuple(image_cond.shape)}")
+        return B
+
     @torch.no_grad()
     def forward(self, x, cond=None, image_cond=None, timesteps=None, context=None, y=None, **kwargs):
         """x [B,4,L], cond [B,8,L], image_cond [B,4,>=R*R], timesteps [B] -> eps [B,out_channels,L]
@@ -260,13 +306,7 @@ class UNetModel(nn.Module):
         assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
         R, T = self.image_size, self.frames
         L = R * R + 2 * T * R
-        if x.dim() != 3 or x.shape[1] != 4 or x.shape[2] != L:
-            raise ValueError(f"x must be [B,4,{L}] for (R,T)=({R},{T}); got {tuple(x.shape)}")
-        B = x.shape[0]
-        if cond is None or tuple(cond.shape) != (B, 8, L):
-            raise ValueError(f"cond must be [B,8,{L}]")
-        if image_cond is None or image_cond.dim() != 3 or image_cond.shape[:2] != (B, 4) or image_cond.shape[2] < R * R:
-            raise ValueError(f"image_cond must be [B,4,>={R * R}]")
+        B = self.check_inputs(x, cond, image_cond)
         dev = x.device
         ctx = self.hip_context(dev, B)
         xf = x.to(torch.float32).contiguous()

@@ -110,6 +110,8 @@ def build(UNetModel, DiffusionWrapper, cfg, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="skip the long base-config sampling runs")
+    ap.add_argument("--add-base-run", default=None, metavar="S[:ratio]",
+                    help="only run one more base-config sampler case (e.g. 250) and ADD it to the existing base.npz")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 8)
     UNetModel, DiffusionWrapper, D = import_reference()
@@ -143,7 +145,7 @@ def main():
     print("schedule.npz written (oracle schedule bit-equal to reference)")
 
     # ---------------------------------------------------------------- narrow + shallow models: forward, taps, sampling
-    for tag, cfg, seed in (("narrow", NARROW_CFG, 11), ("shallow", SHALLOW_CFG, 12)):
+    for tag, cfg, seed in (() if args.add_base_run else (("narrow", NARROW_CFG, 11), ("shallow", SHALLOW_CFG, 12))):
         net = build(UNetModel, DiffusionWrapper, cfg, seed)
         sd = {k: v.clone() for k, v in net.state_dict().items()}
         B = 2
@@ -209,7 +211,15 @@ def main():
     # key/shape manifest of the 804-key checkpoint layout (names + shapes are data, not code)
     out["keys"] = np.array(list(sd.keys()))
     out["shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
-    runs = [(4, None, False)] if args.quick else [(4, None, False), (50, None, False), (100, 0.25, False)]
+    # S=250 is the schedule BASELINE.json's metric is quoted on (ddpm.py:371-375 with sampling_timesteps=250)
+    runs = [(4, None, False)] if args.quick else [(4, None, False), (50, None, False), (100, 0.25, False), (250, None, False)]
+    if args.add_base_run:
+        old = dict(np.load(os.path.join(HERE, "base.npz")))
+        for k in ("eps_t999", "eps_t500", "eps_t0"):
+            assert np.array_equal(old[k], out[k]), f"existing base.npz disagrees on {k}: regenerate everything"
+        out = old
+        sr = args.add_base_run.split(":")
+        runs = [(int(sr[0]), float(sr[1]) if len(sr) > 1 else None, False)]
     for S, ratio, fix in runs:
         with contextlib.redirect_stdout(io.StringIO()):
             dm = D.DDPM(net, channels=4, image_size=32, sampling_timesteps=S, w=0.0)
@@ -230,7 +240,12 @@ def main():
             check(f"base {nm}", zo, z, 1e-4)
     np.savez_compressed(os.path.join(HERE, "base.npz"), **out)
     print("base.npz written")
-    with open(os.path.join(HERE, "PIN_REPORT.txt"), "w") as f:
+    with open(os.path.join(HERE, "PIN_REPORT.txt"), "a" if args.add_base_run else "w") as f:
+        if args.add_base_run:
+            f.write(f"# --add-base-run {args.add_base_run}: reference sample added to base.npz; forwards re-checked bit-equal\n")
+            for k, d in report:
+                f.write(f"{k:44s} {d:.3e}\n")
+            return
         f.write("oracle (oracle/ref_unet.py, oracle/ref_ddpm.py) vs imported reference, max-abs, fp32 CPU\n")
         f.write(f"torch {torch.__version__}, {torch.get_num_threads()} threads\n")
         for k, d in report:

@@ -40,7 +40,7 @@ def _worker(rank, world, port, n_clips, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_clips", [2, 5])
+@pytest.mark.parametrize("n_clips", [1, 2, 5])   # 1: fewer clips than ranks -> rank 1 idles, still gathers
 def test_sharded_sampling_gloo_world2(n_clips):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -113,3 +113,57 @@ def test_batched_per_call_without_process_group_and_shape_check():
         sample_clips_sharded(lambda idx: _fake_batched(idx)[:1], 4, clips_per_call=2)
     with pytest.raises(ValueError):
         sample_clips_sharded(_fake_batched, 4, clips_per_call=0)
+
+
+# ----------------------------------------------------------------------------------------------
+# the real thing on the GPU box: RCCL (backend "nccl") + real DDPM.sample through the sharding helper
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_rccl_world1_real_sampler_matches_unsharded():
+    """BASELINE configs[2] path, as far as one GPU can exercise it: an `nccl` (= RCCL) process group of world size 1
+    on cuda:0, real DDPM.sample calls routed through sample_clips_sharded (clip per call and clips_per_call=2),
+    compared with the un-sharded per-clip results.  The 8-GPU run only adds ranks: there is no other collective."""
+    from conftest import NARROW_CFG
+    from moditalker_amd import DDPM, DiffusionWrapper, UNetModel, filler
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    net = DiffusionWrapper(UNetModel(**NARROW_CFG, frames=16, max_batch=2)).eval()
+    filler.fill_module_(net, seed=11, skip_prefixes=("output_bg_",))
+    net = net.to(dev)
+    S, L, n_clips = 6, 2048, 3
+    dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=S, w=0.0).to(dev)
+    clips = []
+    for i in range(n_clips):
+        x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=40 + i, tag="rccl")
+        noise = filler.noise_list(S, (1, 4, L), seed=40 + i, tag="rccl.noise")
+        clips.append((cond.to(dev), ic.to(dev), [n.to(dev) for n in noise]))
+
+    def one(i):
+        cond, ic, noise = clips[i]
+        return dm.sample(batch_size=1, cond=cond, image_cond=ic, noise=noise)
+
+    def many(idx):
+        cond = torch.cat([clips[i][0] for i in idx])
+        ic = torch.cat([clips[i][1] for i in idx])
+        noise = [torch.cat([clips[i][2][k] for i in idx]) for k in range(S)]
+        return dm.sample(batch_size=len(idx), cond=cond, image_cond=ic, noise=noise)
+
+    plain = [one(i) for i in range(n_clips)]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        sharded = sample_clips_sharded(one, n_clips)
+        assert len(sharded) == n_clips and all(torch.equal(a, b) for a, b in zip(sharded, plain))
+        batched = sample_clips_sharded(many, n_clips, clips_per_call=2)
+        # a different batch size may pick other split-K tilings: fp32 summation-order noise only, over 6 steps
+        assert all(float((a - b).abs().max()) <= 1e-4 for a, b in zip(batched, plain))
+        # the gathered tensors really went through the collective: a second all_gather of a marker tensor works
+        mark = torch.full((4,), 7.0, device=dev)
+        got = [torch.empty_like(mark)]
+        dist.all_gather(got, mark)
+        assert torch.equal(got[0], mark)
+    finally:
+        dist.destroy_process_group()

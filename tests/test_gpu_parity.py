@@ -82,7 +82,8 @@ def test_base_forward_vs_reference_golden():
         assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
 
 
-@pytest.mark.parametrize("S,ratio", [(4, None), (50, None), (100, 0.25)])
+# S=250 is the schedule BASELINE.json's metric is quoted on (ddpm.py:371-375 with sampling_timesteps=250)
+@pytest.mark.parametrize("S,ratio", [(4, None), (50, None), (100, 0.25), (250, None)])
 def test_base_sampler_vs_reference_golden(S, ratio):
     g = np.load(os.path.join(GOLDEN, "base.npz"))
     net = _build(BASE_CFG, 7, max_batch=1)
@@ -247,3 +248,50 @@ def test_errors_are_loud():
     net = net.to(_dev())
     with pytest.raises(ValueError):
         net(x[:, :, :100].to(_dev()), cond.to(_dev()), ic.to(_dev()), torch.tensor([1], device=_dev()))
+
+
+def test_sampler_shape_errors_are_loud():
+    """DDPM.sample hands raw pointers to the C ABI: every shape the reference would reject in torch.cat / broadcasting
+    must be rejected here before the call (_run_ddim had no checks)."""
+    dev = _dev()
+    net = _build(NARROW_CFG, 11)
+    dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=4, w=0.0).to(dev)
+    x, cond, ic = [t.to(dev) for t in filler.synthetic_inputs(2, 32, 16, seed=1, tag="err2")]
+    noise = [z.to(dev) for z in filler.noise_list(4, (2, 4, 2048), seed=1, tag="err2.n")]
+    with pytest.raises(ValueError):
+        dm.sample(batch_size=2, cond=cond[:1], image_cond=ic, noise=noise)             # cond batch != batch_size
+    with pytest.raises(ValueError):
+        dm.sample(batch_size=2, cond=cond, image_cond=ic[:, :, :100], noise=noise)     # image_cond shorter than R*R
+    with pytest.raises(ValueError):
+        dm.sample(batch_size=2, cond=cond, image_cond=ic, noised_start=x[:, :, :1000], ratio_=0.5, noise=noise)
+    with pytest.raises(ValueError):
+        dm.sample(batch_size=2, cond=cond, image_cond=ic, noise=[noise[0]] + [n[:1] for n in noise[1:]])   # draw batch dim
+    with pytest.raises(ValueError):
+        dm.sample(batch_size=2, cond=cond, image_cond=ic, noise=noise[:2])             # too few draws
+    z = dm.sample(batch_size=2, cond=cond, image_cond=ic, noise=noise)                 # and the valid call still runs
+    assert z.shape == (2, 4, 2048)
+
+
+def test_module_copies_and_data_writes():
+    """copy.deepcopy / pickle after a forward (the reference deep-copies the model for its EMA twin, sample.py:226),
+    and the documented invalidate_weights() for writes through .data (which do not bump the version counter)."""
+    import copy
+    import pickle
+    dev = _dev()
+    net = _build(NARROW_CFG, 11)
+    x, cond, ic = [t.to(dev) for t in filler.synthetic_inputs(1, 32, 16, seed=2, tag="cp")]
+    t = torch.tensor([77], device=dev)
+    a = net(x, cond, ic, t)
+    twin = copy.deepcopy(net)
+    assert twin.diffusion_model._ctx is None
+    assert torch.equal(twin(x, cond, ic, t), a)
+    blob = pickle.dumps(net)
+    assert torch.equal(pickle.loads(blob).to(dev)(x, cond, ic, t), a)
+    um = net.diffusion_model
+    um.out[2].weight.data.mul_(0.5)              # .data write: invisible to the fingerprint
+    um.out[2].bias.data.mul_(0.5)
+    um.invalidate_weights()
+    b = net(x, cond, ic, t)
+    assert _maxabs(b, (a * 0.5).cpu()) <= 1e-6   # the head conv is linear in (weight, bias)
+    net.load_state_dict(twin.state_dict())       # load_state_dict invalidates by itself
+    assert torch.equal(net(x, cond, ic, t), a)
