@@ -65,6 +65,10 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=5)
     ap.add_argument("--batched-clips", type=int, default=8,
                     help="extra, informational: steps/s with this many clips batched on ONE GPU (0 = skip); never `value`")
+    ap.add_argument("--ramp-steps", type=int, default=200,
+                    help="untimed denoising steps run BEFORE the warm-up so that plan build, tile tuning, graph capture and the "
+                         "GPU's clock ramp (DVFS: a cold MI355X runs its first ~100 ms well below its sustained clock) all "
+                         "happen outside the timed region; set-up, not steps")
     ap.add_argument("--res", type=int, default=32, choices=(32, 64),
                     help="latent resolution R: 32 = BASELINE configs[1] (the metric's workload), 64 = configs[3] (512x512 clip)")
     args = ap.parse_args()
@@ -101,7 +105,7 @@ def main():
     cond = torch.rand(1, 8, L, generator=g, device=dev) * 2 - 1
     image_cond = torch.rand(1, 4, R * R, generator=g, device=dev) * 2 - 1
     x = torch.randn(1, 4, L, generator=g, device=dev)
-    n_noise = max(K, W, 1)
+    n_noise = max(K, W, args.ramp_steps, 1)
     noise = torch.randn(n_noise, 1, 4, L, generator=g, device=dev)
     if os.environ.get("MTV_EAGER") == "1":
         um.set_eager(True)                       # plain launches instead of hipGraph replay
@@ -121,8 +125,10 @@ def main():
         torch.cuda.synchronize(dev)
 
     xw = x.clone()
-    run(max(W, 1), xw)                            # warm-up: builds the plan, auto-tunes, captures the graph
-                                                  # (at least one step even for --warmup 0: set-up is not a step)
+    run(max(args.ramp_steps, 1), xw)              # set-up: builds the plan, loads/tunes tiles, captures the graphs, ramps clocks
+    torch.cuda.synchronize(dev)
+    if W > 0:
+        run(W, xw)                                # the W untimed warm-up steps of the contract
     barrier()
     xt = x.clone()
     t0 = time.perf_counter()
@@ -142,7 +148,7 @@ def main():
     if rank == 0:
         work = um.work(dev)
         # ---- roofline of the dominant kernel family, measured live with hipEvents around every launch
-        prof = um.profile_forward(1, args.profile_iters, dev)
+        prof = um.profile_forward(1, args.profile_iters, dev, step=True)   # the launches of one SAMPLER step
         fam = {}
         for p in prof:
             key = p["name"].split(":")[0]
@@ -172,12 +178,13 @@ def main():
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         # HBM bytes per launch from the PMC passes (cannot be collected inside this process): the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this same command, gfx950 correction applied
+        # (a constant of the committed profile, NOT a measurement of this run: `traffic_source.kind` says so)
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
             e = pmc[dom_name]
             traffic = round((2.0 * e["fetch_raw_MB_per_step"] + e["write_raw_MB_per_step"]) * 1e6 / e["launches_per_step"])
-            traffic_src = pmc["source"]
+            traffic_src = dict(kind="committed", collected=pmc.get("collected"), commit=pmc.get("commit"), detail=pmc["source"])
         except (OSError, KeyError, ValueError):
             pass
         roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TF,
@@ -187,10 +194,22 @@ def main():
                         avg_launch_us_with_event_overhead=round(1e3 * dom["ms_raw"] / max(1, dom["launches"]), 3),
                         event_overhead_us_per_launch=round(1e3 * ev_ms, 3),
                         algorithmic_bytes_per_launch=round(dom["bytes"] / max(1, dom["launches"])),
-                        flops_per_step=dom["flops"],
-                        hbm_view=dict(algorithmic_bytes_per_step=dom["bytes"],
-                                      achieved_GBs=round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1) if dom["ms"] > 0 else 0.0,
-                                      peak_GBs=HBM_PEAK_GBS))
+                        flops_per_step=dom["flops"])
+        # the HBM side of the same family, with BOTH byte definitions: SURVEY section 8(d)'s "fused conv/GN path"
+        # (3x3 conv weights + fused 1x1 skip weights + their activations: 477 MB at configs[1]) and this build's wider
+        # one (every k_conv launch incl. qkv/proj: weights once + activations in/out once)
+        conv3 = fam.get("conv3", dict(ms=0.0, bytes=0.0))
+        b8d = work["bytes_weights_conv"] + work["bytes_act_conv_path"]
+        roofline["hbm_view"] = dict(
+            peak_GBs=HBM_PEAK_GBS,
+            survey_8d=dict(what="conv3x3 (+fused 1x1 skip) launches: weights once + activations in/out once",
+                           algorithmic_bytes_per_step=b8d, ms_per_step=round(conv3["ms"], 4),
+                           achieved_GBs=round(b8d / (conv3["ms"] * 1e-3) / 1e9, 1) if conv3["ms"] > 0 else 0.0,
+                           frac=round(b8d / (conv3["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if conv3["ms"] > 0 else 0.0),
+            all_k_conv=dict(what="every k_conv launch (3x3, 1x1 skip, qkv, proj_out)",
+                            algorithmic_bytes_per_step=dom["bytes"] if dom_name == "k_conv" else conv["bytes"],
+                            achieved_GBs=round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1) if conv["ms"] > 0 else 0.0,
+                            frac=round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if conv["ms"] > 0 else 0.0))
         families = {k: dict(ms_per_step=round(v["ms"], 4), launches=v["launches"],
                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] else None)
                     for k, v in fam.items()}
@@ -218,27 +237,35 @@ def main():
                     img = x0 * an.sqrt() + c * eps + sigma * nz[i]
                 return img
 
-            # the box has far more cores than this small-batch workload can use: probe a few thread counts
-            # with one step each and time the sample with the best one (reported as `cores`)
-            cand = sorted({t for t in (8, 16, 32, 64, ncores) if t <= ncores})
-            best_t, best_dt = cand[0], 1e30
-            torch.set_num_threads(cand[0])
+            # BASELINE.md section 3's rule: torch.set_num_threads(<physical cores of the box>) -- that is `value`.
+            # This B=1 workload cannot use that many threads (oneDNN/bmm at 2048 tokens scale to ~8-16), so the
+            # best of a small probe is reported beside it as `best_threads` (never instead of it).
+            torch.set_num_threads(ncores)
             cpu_steps(1, xc)                      # warm-up (allocator, oneDNN primitives)
-            for tcount in cand:
-                torch.set_num_threads(tcount)
-                t1 = time.perf_counter()
-                cpu_steps(1, xc)
-                d1 = time.perf_counter() - t1
-                if d1 < best_dt:
-                    best_t, best_dt = tcount, d1
-            torch.set_num_threads(best_t)
             tc = time.perf_counter()
             cpu_steps(args.cpu_steps, xc)
             tc = time.perf_counter() - tc
-            cpu = dict(value=round(args.cpu_steps / tc, 4), unit="denoise-steps/s", cores=best_t, kind="port",
-                       sample=f"first {args.cpu_steps} of the 250 DDIM steps of the same clip (after warm-up; thread count "
-                              f"chosen from {cand} by a 1-step probe, host has {os.cpu_count()} logical CPUs), "
-                              f"oracle/ref_unet.py op-for-op PyTorch {torch.__version__} CPU restatement, fp32")
+            cand = sorted({t for t in (8, 16, 32) if t < ncores})
+            best_t, best_dt = None, 1e30
+            for tcount in cand:
+                torch.set_num_threads(tcount)
+                cpu_steps(1, xc)
+                t1 = time.perf_counter()
+                cpu_steps(2, xc)
+                d1 = (time.perf_counter() - t1) / 2
+                if d1 < best_dt:
+                    best_t, best_dt = tcount, d1
+            model = ""
+            try:
+                model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except (OSError, IndexError):
+                pass
+            cpu = dict(value=round(args.cpu_steps / tc, 4), unit="denoise-steps/s", cores=ncores, kind="port",
+                       sample=f"first {args.cpu_steps} of the 250 DDIM steps of the same clip after 1 warm-up step, "
+                              f"torch.set_num_threads({ncores}) = physical cores (BASELINE.md section 3; {os.cpu_count()} logical CPUs, "
+                              f"{model}), oracle/ref_unet.py op-for-op PyTorch {torch.__version__} CPU restatement, fp32",
+                       best_threads=dict(threads=best_t, value=round(1.0 / best_dt, 4),
+                                         sample=f"2 steps each at {cand} threads") if best_t else None)
         # ---- informational only: the same loop with several clips batched on this GPU (amortises the
         # per-launch floor and the weight stream; NOT the BASELINE workload, never `value`)
         batched = None
@@ -265,7 +292,7 @@ def main():
             runb(nsb)
             torch.cuda.synchronize(dev)
             tb = time.perf_counter() - tb
-            pb = netb.diffusion_model.profile_forward(Bc, 3, dev)
+            pb = netb.diffusion_model.profile_forward(Bc, 3, dev, step=True)
             cms = sum(p["ms"] for p in pb if p["name"].startswith("conv"))
             cfl = sum(p["flops"] for p in pb if p["name"].startswith("conv"))
             ams = sum(p["ms"] for p in pb if p["name"].startswith("attn"))
@@ -285,6 +312,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
+            "ramp_steps_untimed": args.ramp_steps,
             "ms_per_step": round(1e3 * dt / K, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -297,7 +325,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "step_ms_sum_of_launches": round(step_ms_events, 4),
-            "launches_per_step": work["n_launches"] + 2,
+            "launches_per_step": work["n_launches_step"],
             "flops_per_step": {k: work[k] for k in ("flops_conv3x3", "flops_1x1", "flops_attn_core", "flops_linear")},
             "families": families,
             "roofline_attention": attn_roof,

@@ -100,7 +100,9 @@ typedef struct mtv_ddim_step {
  *   x_io      [B,4,L]  in: x_T (or the q_sample'd start); out: the clamped x0 of the last step
  *   noise     [n_noise,B,4,L] explicit N(0,1) draws (the reference draws them from torch's global
  *             generator inside the loop; the Python wrapper owns that RNG)
- * The whole step is replayed as one hipGraph per step; steps are device-resident (no host sync). */
+ * A step is ONE hipGraph replay and consists of the UNet's launches only: the FiLM rows of all steps are computed
+ * once per call, the DDIM update and the hand-over to the next step (step counter, packed input, FiLM row,
+ * statistics arena) run inside the head conv; steps are device-resident (no host synchronisation in the loop). */
 int mtv_ddim_sample(mtv_ctx* ctx, float* x_io, const float* cond, const float* image_cond,
                     int image_cond_len, const float* noise, int n_noise,
                     const mtv_ddim_step* steps, int n_steps, int batch, void* stream);
@@ -113,7 +115,8 @@ int mtv_debug_tap(mtv_ctx* ctx, const char* name, float* dst, int64_t dst_cap_fl
 typedef struct mtv_work {
     double flops_conv3x3, flops_1x1, flops_attn_core, flops_linear;
     double bytes_weights_conv, bytes_weights_other, bytes_act_conv_path;
-    int32_t n_launches;
+    int32_t n_launches;        /* launches of one mtv_forward (time-embedding chain + packing + UNet) */
+    int32_t n_launches_step;   /* launches of one sampler step inside mtv_ddim_sample (UNet launches only) */
 } mtv_work;
 int mtv_get_work(const mtv_ctx* ctx, mtv_work* out);
 
@@ -127,6 +130,13 @@ typedef struct mtv_op_time {
     double bytes;
 } mtv_op_time;
 int mtv_profile_forward(mtv_ctx* ctx, int batch, int iters, mtv_op_time* out, int cap, int* n_out, void* stream);
+/* The same for one SAMPLER STEP (the launch sequence mtv_ddim_sample replays per step: UNet launches only, the
+ * DDIM update inside the head conv).  Runs on the context's own staging buffers with a one-entry step table. */
+int mtv_profile_step(mtv_ctx* ctx, int batch, int iters, mtv_op_time* out, int cap, int* n_out, void* stream);
+
+/* Diagnostic build only (conv.hip compiled with -DMTV_ABLATE=64, MTV_STAMPS=1 in the environment): one sampler step
+ * with plain launches; the in-kernel phase timestamps of four sampled workgroups per conv are written to `path`. */
+int mtv_debug_stamps(mtv_ctx* ctx, int batch, const char* path, void* stream);
 
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
 int mtv_set_eager(mtv_ctx* ctx, int eager);

@@ -14,7 +14,8 @@ from typing import Optional
 MTV_OK = 0
 MTV_IGNORED = 1
 MTV_MAX_LEVELS = 8
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtv_hip.so")
+# (MTV_LIB: load another build of the same library, e.g. the phase-timestamp diagnostic build libmtv_hip_stamp.so)
+LIB_PATH = os.environ.get("MTV_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtv_hip.so")
 
 
 class MtvError(RuntimeError):
@@ -61,6 +62,7 @@ class MtvWork(C.Structure):
         ("bytes_weights_other", C.c_double),
         ("bytes_act_conv_path", C.c_double),
         ("n_launches", C.c_int32),
+        ("n_launches_step", C.c_int32),
     ]
 
 
@@ -85,6 +87,8 @@ SYMBOLS = [
     ("mtv_get_work", C.c_int, [_P, C.POINTER(MtvWork)]),
     ("mtv_set_eager", C.c_int, [_P, C.c_int]),
     ("mtv_profile_forward", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(MtvOpTime), C.c_int, C.POINTER(C.c_int), _P]),
+    ("mtv_profile_step", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(MtvOpTime), C.c_int, C.POINTER(C.c_int), _P]),
+    ("mtv_debug_stamps", C.c_int, [_P, C.c_int, C.c_char_p, _P]),
     ("mtv_selftest_geometry", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_gather_index", C.c_int, [C.c_int] * 6),
 ]

@@ -62,8 +62,9 @@ struct SegDesc {              // 32 bytes, one per segment, in LDS
 
 __device__ __forceinline__ int usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-#if MTV_ABLATE & 64   // phase timestamps (shader clock) of thread 0 of four blocks -> a.dbg (conv_bench)
-#define MTV_STAMP(k) do { if (tid == 0 && blockIdx.x < 4) a.dbg[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#if MTV_ABLATE & 64   // phase timestamps of thread 0 of four sampled blocks (first two, middle, last) -> a.dbg (conv_bench, MTV_STAMPS)
+#define MTV_STAMP(k) do { if (threadIdx.x == 0 && a.dbg) { const int sb_ = blockIdx.x < 2 ? (int)blockIdx.x : (blockIdx.x == gridDim.x / 2 ? 2 : (blockIdx.x == gridDim.x - 1 ? 3 : -1)); \
+                          if (sb_ >= 0) a.dbg[sb_ * 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define MTV_STAMP(k) do { } while (0)
 #endif
@@ -216,6 +217,7 @@ __device__ __forceinline__ void stat_add(const ConvArgs& a, int b, int sg, int n
 
 template <int MT, int NT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
+    MTV_STAMP(7);
     touch_kernargs<(int)sizeof(ConvArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float2 s_mr[3][32];
@@ -225,6 +227,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     const int i = lane & 15, q = lane >> 4;
     constexpr int ROWS = 16 * MT, COLS = 16 * NT, NTH = NW * 64;
     const int tiles_per_b = (a.Lout + ROWS - 1) / ROWS;
+    // ---- sampler-step head (mtv_internal.h DdimFuse): the hand-over record and the step index are requested at
+    // entry and used once this workgroup's operand ring is in flight (head_duties below), so their latency is hidden
+    const DdimFuse* dd = a.ddim;
+    DdimFuse ddv{};
+    int step_now = 0;
+    if (dd) {
+        ddv = *dd;
+        step_now = *a.step_counter;
+    }
     // block -> (row tile, column tile, K slice).  The dispatcher round-robins consecutive workgroups over
     // the 8 XCDs (private L2s).  xmap 0: row tiles vary fastest (every L2 sees the whole -- small -- weight
     // matrix).  xmap 1, for weight-dominated layers: workgroup id % 8 selects the (column tile, K slice)
@@ -363,6 +374,19 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         }
     }
 
+    DdimStep stp{};
+    if (dd) {
+        // every workgroup of the launch zeroes its slice of the OTHER parity's statistics arena and copies its slice
+        // of the next step's FiLM row (nobody reads either any more in this step): fire-and-forget stores that
+        // drain under the conv itself; the step's scalars are fetched for the epilogue
+        for (long long e = (long long)blockIdx.x * NTH + tid; e < ddv.zero_vec4; e += (long long)gridDim.x * NTH)
+            *reinterpret_cast<f32x4*>(ddv.zero_arena + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (step_now + 1 < ddv.n_steps) {
+            const float* src = ddv.film_tab + (size_t)(step_now + 1) * ddv.film_total;
+            for (int e = blockIdx.x * NTH + tid; e < ddv.film_total; e += gridDim.x * NTH) ddv.film_out[e] = src[e];
+        }
+        stp = ddv.steps[step_now];
+    }
     MTV_STAMP(1);
     if (!no_tab) build_idx();
     if (do_gn) {
@@ -650,13 +674,32 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
         } else {
             for (int k = 0; k < 4 && n + k < a.N; ++k) {
-                if (a.out_cm) a.out[((size_t)b * a.N + n + k) * a.Lout + tok] = v[k];
+                if (dd) {
+                    // sampler-step head (N == 4 == the sample's channels): v is eps; x <- DDIM update, in the external
+                    // layout and as channels 0..3 of the packed input of the next step's stem conv
+                    const size_t ix = ((size_t)b * a.N + n + k) * a.Lout + tok;
+                    const float nz = stp.noise_index >= 0 ? ddv.noise[(size_t)stp.noise_index * ddv.n_per_draw + ix] : 0.f;
+                    const float xn = ddim_update_elem(stp, ddv.x[ix], v[k], nz);
+                    ddv.x[ix] = xn;
+                    ddv.h0[((size_t)b * a.Lout + tok) * 16 + n + k] = xn;
+                } else if (a.out_cm) a.out[((size_t)b * a.N + n + k) * a.Lout + tok] = v[k];
                 else a.out[((size_t)b * a.Lout + tok) * a.N + n + k] = v[k];
             }
         }
         if (want_stats) *reinterpret_cast<f32x4*>(fin + rr * LDR + cq * 4) = v;
     }
     MTV_STAMP(5);
+    if (dd) {
+        // the workgroup that arrives last advances the step counter: every workgroup of the launch has read the
+        // counter (entry duties, step record) before its own arrival, so none can see the new value
+        __syncthreads();
+        if (tid == 0) {
+            if (__hip_atomic_fetch_add(ddv.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.B * tiles_per_b * tiles_n - 1) {
+                __hip_atomic_store(ddv.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ddv.counter, step_now + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if (!want_stats) return;
 
     // ---- pass 2 (column-major over the tile): GroupNorm statistics of the output for its consumers.
@@ -734,6 +777,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             atomicAdd(dst + 1, ss);
         }
     }
+    MTV_STAMP(6);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -831,7 +875,9 @@ static hipError_t launch_conv_nw(const ConvArgs& a, int NW, hipStream_t s) {
         case 2: return launch_conv_t<MT, NT, 2>(a, s);
         case 4: return launch_conv_t<MT, NT, 4>(a, s);
         case 8: return launch_conv_t<MT, NT, 8>(a, s);
-        case 16: return launch_conv_t<MT, NT, 16>(a, s);
+        case 16:
+            if constexpr (MT * NT >= 8) return hipErrorInvalidValue;   // 1024-thread blocks cap VGPRs at 128: these would spill
+            else return launch_conv_t<MT, NT, 16>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -848,7 +894,8 @@ static hipError_t conv_attr_nw() {
     if ((e = conv_attr<MT, NT, 2>()) != hipSuccess) return e;
     if ((e = conv_attr<MT, NT, 4>()) != hipSuccess) return e;
     if ((e = conv_attr<MT, NT, 8>()) != hipSuccess) return e;
-    return conv_attr<MT, NT, 16>();
+    if constexpr (MT * NT >= 8) return hipSuccess;
+    else return conv_attr<MT, NT, 16>();
 }
 // Dynamic LDS above 64 KB must be opted into once per kernel; done at mtv_create (never under capture).
 hipError_t conv_init_attrs() {
@@ -866,6 +913,10 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
     a.KS = t.KS;
     a.xmap = t.XM;
     if (a.KS > 1 && (!a.slab || !a.tickets || (a.N & 3))) return hipErrorInvalidValue;
+    if (a.ddim) {
+        if (!a.out_cm || a.N != 4) return hipErrorInvalidValue;
+        a.xmap = 0;            // no padding blocks: every block of the grid takes part in the step hand-over
+    }
     hipError_t e = hipErrorInvalidValue;
     if (t.MT == 4 && t.NT == 4) e = launch_conv_nw<4, 4>(a, t.NW, s);
     else if (t.MT == 2 && t.NT == 4) e = launch_conv_nw<2, 4>(a, t.NW, s);

@@ -492,53 +492,81 @@ hipError_t launch_pack_input(const float* x, const float* cond, const float* ima
 }
 
 // =====================================================================================
-// DDIM update (ddpm.py:278-282,346-351,386-398), eta-general, separate roundings like the reference
+// Sampler set-up, once per mtv_ddim_sample call.  The DDIM update itself (ddpm.py:278-282,346-351,386-398) runs
+// in the head conv's epilogue (conv.hip, ddim_update_elem); nothing but UNet launches remains inside a step.
 // =====================================================================================
-__global__ void k_ddim_update(float* x, const float* eps, const float* noise, const DdimStep* steps,
-                              const int* counter, int64_t n_per_draw, int64_t n) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const DdimStep st = steps[*counter];
-    const float e = eps[idx];
-    float x0 = __fsub_rn(__fmul_rn(st.sqrt_recip_ac, x[idx]), __fmul_rn(st.sqrt_recipm1_ac, e));
-    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-    if (st.last) {
-        x[idx] = x0;
-        return;
-    }
-    const float nz = st.noise_index >= 0 ? noise[(int64_t)st.noise_index * n_per_draw + idx] : 0.f;
-    x[idx] = __fadd_rn(__fadd_rn(__fmul_rn(x0, st.sqrt_ac_next), __fmul_rn(st.c, e)), __fmul_rn(st.sigma, nz));
+// timestep_embedding of EVERY step's t at once: row i = [cos(t_i * f) | sin(t_i * f)]
+__global__ void k_step_sinusoid(const DdimStep* steps, int n_steps, const float* freqs, float* out, int half) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_steps * half) return;
+    const int i = idx / half, k = idx - i * half;
+    const float arg = (float)(int64_t)steps[i].t * freqs[k];
+    out[(size_t)i * 2 * half + k] = cosf(arg);
+    out[(size_t)i * 2 * half + half + k] = sinf(arg);
 }
 
-hipError_t launch_ddim_update(float* x, const float* eps, const float* noise, const DdimStep* steps,
-                              const int* counter, int64_t n_per_draw, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_ddim_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, eps, noise, steps, counter, n_per_draw, n);
+hipError_t launch_step_sinusoid(const DdimStep* steps, int n_steps, const float* freqs, float* out, int half, hipStream_t s) {
+    hipLaunchKernelGGL(k_step_sinusoid, dim3((n_steps * half + 255) / 256), dim3(256), 0, s, steps, n_steps, freqs, out, half);
     return hipGetLastError();
 }
 
-__global__ void k_ddim_advance(const DdimStep* steps, int* counter, int n_steps, int64_t* tbuf, int B) {
-    __shared__ int nxt;
-    if (threadIdx.x == 0) {
-        nxt = *counter + 1;
-        *counter = nxt;
+// k_linear for many input rows (the time-embedding MLP and the FiLM matrix applied to all steps of a sampler call):
+// a wave owns one output feature n and RB = 8 rows, so W is streamed once per 8 rows instead of once per row.
+// Per (row, n) the arithmetic is k_linear's, operation for operation (same lane partition of K, same shuffle tree),
+// so a step's FiLM row is bit-identical to what the per-step launches of mtv_forward compute.
+__global__ __launch_bounds__(256) void k_linear_rows(const LinearArgs a) {
+    constexpr int RB = 8;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    const int b0 = blockIdx.y * RB;
+    if (n >= a.N) return;
+    const float* w = a.W + (size_t)n * a.K;
+    float acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+    for (int k = lane * 4; k < a.K; k += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = b0 + r < a.B ? b0 + r : a.B - 1;       // (rows past the end recompute the last one; never stored)
+            f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + (size_t)row * a.K + k);
+            if (a.act_in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = silu_f(xv[e]);
+            }
+            acc[r] = fmaf(xv[0], wv[0], acc[r]);
+            acc[r] = fmaf(xv[1], wv[1], acc[r]);
+            acc[r] = fmaf(xv[2], wv[2], acc[r]);
+            acc[r] = fmaf(xv[3], wv[3], acc[r]);
+        }
     }
-    __syncthreads();
-    if (nxt < n_steps)
-        for (int b = threadIdx.x; b < B; b += blockDim.x) tbuf[b] = steps[nxt].t;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && b0 + r < a.B) a.out[(size_t)(b0 + r) * a.out_stride + n] = v + a.bias[n];
+    }
 }
 
-hipError_t launch_ddim_advance(const DdimStep* steps, int* counter, int n_steps, int64_t* tbuf, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_ddim_advance, dim3(1), dim3(64), 0, s, steps, counter, n_steps, tbuf, B);
+hipError_t launch_linear_rows(const LinearArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_linear_rows, dim3((a.N + 3) / 4, (a.B + 7) / 8), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-__global__ void k_ddim_init(const DdimStep* steps, int* counter, int64_t* tbuf, int B) {
-    if (threadIdx.x == 0) *counter = 0;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) tbuf[b] = steps[0].t;
+// step counter <- 0, arrival counter <- 0, FiLM row of step 0 -> film_out
+__global__ void k_ddim_init(const DdimFuse* f) {
+    const DdimFuse d = *f;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) {
+        *d.counter = 0;
+        *d.done = 0;
+    }
+    for (int e = idx; e < d.film_total; e += gridDim.x * blockDim.x) d.film_out[e] = d.film_tab[e];
 }
 
-hipError_t launch_ddim_init(const DdimStep* steps, int* counter, int64_t* tbuf, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_ddim_init, dim3(1), dim3(64), 0, s, steps, counter, tbuf, B);
+hipError_t launch_ddim_init(const DdimFuse* f, hipStream_t s) {
+    hipLaunchKernelGGL(k_ddim_init, dim3(64), dim3(256), 0, s, f);
     return hipGetLastError();
 }
 

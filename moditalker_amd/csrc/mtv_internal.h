@@ -39,6 +39,28 @@ struct StatOut {
     int coff;
 };
 
+struct DdimStep;
+
+// Sampler-step duties of the HEAD conv (the last launch of a denoising step): its epilogue applies the eta-general
+// DDIM update to the sample it has just predicted eps for, and the launch also prepares the NEXT step -- so a
+// step is exactly the UNet's own launches, replayed as one hipGraph (no k_ddim_update / k_ddim_advance /
+// k_pack_input / time-embedding / memset launches).  Lives in device memory (rewritten per mtv_ddim_sample call:
+// graph kernel arguments are frozen, this record is not).
+struct DdimFuse {
+    float* x;                 // [B][4][L] current sample, external layout; updated in place (ddpm.py:386-398)
+    float* h0;                // [B][L][16] packed UNet input: channels 0..3 <- the new sample (unet.py:1022-1025)
+    const float* noise;       // [n][B][4][L] in-loop N(0,1) draws
+    const DdimStep* steps;    // per-step scalars
+    int* counter;             // index of the current step; advanced by the head's last workgroup
+    int* done;                // arrival counter of the head's workgroups (zero between launches)
+    long long n_per_draw;     // B*4*L
+    const float* film_tab;    // [n_steps][film_total] FiLM rows of every step (t is the same for all clips of a call)
+    float* film_out;          // [film_total] the row the ResBlocks read; this launch copies row counter+1 into it
+    int film_total, n_steps;
+    float* zero_arena;        // the OTHER step parity's GroupNorm statistics arena: zeroed here for the next step
+    long long zero_vec4;      // ... its size in 16-byte units
+};
+
 struct ConvArgs {
     const float* src[4];  // [0..1]: tapped sources (<=2, concatenated along channels);
     int C[4];             // [2..3]: raw sources of the fused 1x1 skip conv (<=2)
@@ -75,6 +97,8 @@ struct ConvArgs {
     // 2 = 3x3 taps on the nearest-x2-upsampled source.  geo_skip: 0 = `gather_skip` table / identity,
     // 2 = nearest-x2-upsampled source.  (geo_r, geo_t) = output-level plane geometry.
     int geo_main, geo_skip, geo_r, geo_t;
+    const DdimFuse* ddim;    // sampler-step head only (nullptr otherwise)
+    const int* step_counter; // ... the device-side step index (DdimFuse::counter; here too so it is loaded at entry)
     unsigned long long* dbg; // phase timestamps for tools/ubench/conv_bench (nullptr in the product)
 };
 
@@ -174,6 +198,18 @@ struct DdimStep {            // mirror of mtv_ddim_step (include/mtv_hip.h)
     int32_t noise_index;
 };
 
+#if defined(__HIPCC__)
+// One element of the eta-general DDIM update (ddpm.py:278-282 predict_start_from_noise, :346-351 clamp, :386-398):
+// x0 = clamp(sqrt(1/ac)*x - sqrt(1/ac - 1)*eps, -1, 1);  last step: x <- x0;  else
+// x <- x0*sqrt(ac_next) + c*eps + sigma*noise, with the reference's separate roundings (no contraction).
+__device__ __forceinline__ float ddim_update_elem(const DdimStep& st, float x, float e, float nz) {
+    float x0 = __fsub_rn(__fmul_rn(st.sqrt_recip_ac, x), __fmul_rn(st.sqrt_recipm1_ac, e));
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    if (st.last) return x0;
+    return __fadd_rn(__fadd_rn(__fmul_rn(x0, st.sqrt_ac_next), __fmul_rn(st.c, e)), __fmul_rn(st.sigma, nz));
+}
+#endif
+
 // ---- launchers (kernels.hip) ----
 struct ConvTile { int MT, NT, NW, KS, XM; };   // XM: workgroup->tile mapping (0 rows fastest, 1 weight slice per XCD)
 ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn);
@@ -187,10 +223,10 @@ hipError_t launch_linear(const LinearArgs& a, hipStream_t s);
 hipError_t launch_time_sinusoid(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
 hipError_t launch_pack_input(const float* x, const float* cond, const float* image_cond, int ic_len,
                              float* out, int B, int L, int RR, hipStream_t s);
-hipError_t launch_ddim_update(float* x, const float* eps, const float* noise, const DdimStep* steps,
-                              const int* counter, int64_t n_per_draw, int64_t n, hipStream_t s);
-hipError_t launch_ddim_advance(const DdimStep* steps, int* counter, int n_steps, int64_t* tbuf, int B, hipStream_t s);
-hipError_t launch_ddim_init(const DdimStep* steps, int* counter, int64_t* tbuf, int B, hipStream_t s);
+// sampler set-up (once per mtv_ddim_sample call; the steps themselves are UNet launches only)
+hipError_t launch_step_sinusoid(const DdimStep* steps, int n_steps, const float* freqs, float* out, int half, hipStream_t s);
+hipError_t launch_linear_rows(const LinearArgs& a, hipStream_t s);   // k_linear for many rows: W read once per 8 rows
+hipError_t launch_ddim_init(const DdimFuse* f, hipStream_t s);
 hipError_t launch_repack_conv(const float* src, float* dst, int N, int C, int ntaps, int ld, hipStream_t s);
 
 }  // namespace mtv

@@ -5,6 +5,9 @@
 // the plan is MI355X-first: one token-major channels-last buffer per activation, planes batched in
 // every launch, skip concatenations expressed as two-source K loops, timestep FiLM for all
 // ResBlocks in one GEMV, the whole step replayed as one hipGraph with a device-side step counter.
+#include <dlfcn.h>
+
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -87,8 +90,16 @@ struct ConvOp {                 // one convolution of the plan; args/tile are pa
     int op_index = -1;
 };
 
+// A plan is built per (batch size, mode).  FORWARD: one UNetModel.forward for arbitrary per-clip timesteps
+// (time-embedding chain + input packing + UNet -> eps).  STEP0 / STEP1: one denoising step of the sampler, UNet
+// launches ONLY -- FiLM rows come from a per-call table, the sample is packed by the previous step's head conv,
+// the DDIM update runs in the head conv's epilogue; the two differ in the GroupNorm statistics arena they use
+// (a step's head zeroes the other parity's arena, so no memset launch either).
+enum Mode { MODE_FORWARD = 0, MODE_STEP0 = 1, MODE_STEP1 = 2 };
+
 struct Plan {
     int B = 0;
+    int mode = MODE_FORWARD;
     std::vector<std::shared_ptr<ConvOp>> convs;
     bool tuned = false;
     std::vector<Op> ops;           // UNet forward
@@ -114,18 +125,26 @@ struct mtv_ctx {
     std::vector<void*> allocs;
     std::vector<int*> g3, gup3, gup1;           // gather tables per level
     bool geo_ok = true;                         // geo_source() reproduced every table on the host (mtv_create)
-    double* stats = nullptr;                     // GN site arena
-    size_t stats_bytes = 0;
-    size_t stats_copy_doubles = 0;              // doubles per privatised copy of the arena
+    double* stats = nullptr;                     // GN site arenas: [2 step parities][STAT_COPIES][sites][max_batch][3][32][2]
+    size_t stats_bytes = 0;                     // bytes of ONE arena
+    size_t stats_copy_doubles = 0;              // doubles per privatised copy of an arena
     int site_cursor = 0;
+    int site_parity = 0;                        // arena the plan being built uses
     float* freqs = nullptr;
     // external-layout staging (channel-major) and sampler state
     float *xin = nullptr, *condin = nullptr, *icin = nullptr, *eps = nullptr;
     int64_t* tbuf = nullptr;
+    // sampler state (mtv_ddim_sample): step table, per-call FiLM table, the head conv's hand-over records
     DdimStep* d_steps = nullptr;
+    float *film_tab = nullptr, *sin_steps = nullptr, *e0_steps = nullptr, *e1_steps = nullptr;
     int d_steps_cap = 0;
-    int* d_counter = nullptr;
-    std::map<int, std::unique_ptr<Plan>> plans;
+    int* d_counter = nullptr;                   // [0] step index, [1] arrival counter of the head's workgroups
+    DdimFuse* d_fuse = nullptr;                 // [2]: one per step parity
+    char* h_pin[2] = {nullptr, nullptr};        // pinned upload staging (step table + hand-over records), double buffered
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    unsigned pin_turn = 0;
+    std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;   // (batch, mode)
     hipStream_t cap_stream = nullptr;
     bool eager = false;
     mtv_work work{};
@@ -176,9 +195,34 @@ struct mtv_ctx {
         return p;
     }
     double* new_site() {
-        double* p = stats + (size_t)site_cursor * cfg.max_batch * 192;
+        double* p = stats + (size_t)site_parity * stats_copy_doubles * STAT_COPIES + (size_t)site_cursor * cfg.max_batch * 192;
         ++site_cursor;
         return p;
+    }
+    ~mtv_ctx() {     // every exit path of mtv_create / mtv_destroy ends here: nothing device-side outlives the context
+        int cur = 0;
+        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != device;
+        if (sw) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        for (auto& kv : plans)
+            if (kv.second->g_forward) (void)hipGraphExecDestroy(kv.second->g_forward);
+        plans.clear();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        for (void* p : allocs) (void)hipFree(p);
+        if (staging) (void)hipFree(staging);
+        free_step_tables();
+        for (int i = 0; i < 2; ++i) {
+            if (h_pin[i]) (void)hipHostFree(h_pin[i]);
+            if (pin_ev[i]) (void)hipEventDestroy(pin_ev[i]);
+        }
+        if (sw) (void)hipSetDevice(cur);
+    }
+    void free_step_tables() {
+        for (void* p : {(void*)d_steps, (void*)film_tab, (void*)sin_steps, (void*)e0_steps, (void*)e1_steps})
+            if (p) (void)hipFree(p);
+        d_steps = nullptr;
+        film_tab = sin_steps = e0_steps = e1_steps = nullptr;
+        d_steps_cap = 0;
     }
 };
 
@@ -373,13 +417,16 @@ struct Builder {
     mtv_ctx* c;
     Plan* plan;
     int B;
+    int mode;
     const mtv_config& f;
     int emb;
-    float* film_out;     // [maxB][film_total]
+    float* film_out;     // FORWARD: [maxB][film_total]; sampler step: [film_total] shared by every clip of the call
+    int film_stride;     // floats between batch elements of film_out (0 in a sampler step)
     std::string err;
     std::map<const float*, std::shared_ptr<ConvOp>> producer;   // tensor -> the conv that writes it
 
-    Builder(mtv_ctx* ctx, Plan* p, int batch) : c(ctx), plan(p), B(batch), f(ctx->cfg), emb(ctx->emb_dim), film_out(nullptr) {}
+    Builder(mtv_ctx* ctx, Plan* p, int batch, int md)
+        : c(ctx), plan(p), B(batch), mode(md), f(ctx->cfg), emb(ctx->emb_dim), film_out(nullptr), film_stride(0) {}
 
     void push(const std::string& name, std::function<hipError_t(hipStream_t)> fn, double flops = 0.0, double bytes = 0.0) {
         Op op;
@@ -436,6 +483,8 @@ struct Builder {
         }
         const int nchunks = a0.ntaps * (a0.Cmain / 16) + a0.Cskip / 16;
         account_conv(a0);
+        static const bool stamps_env = getenv("MTV_STAMPS") != nullptr;      // diagnostic build only (mtv_debug_stamps)
+        if (stamps_env) a0.dbg = reinterpret_cast<unsigned long long*>(c->buf("dbg." + name + "." + std::to_string(mode) + "." + std::to_string(B), 64));
         auto op = std::make_shared<ConvOp>();
         op->a = a0;
         op->t = conv_pick_tile(B, a0.Lout, a0.N, nchunks, a0.Cmain, a0.gn.sums != nullptr);
@@ -547,7 +596,7 @@ struct Builder {
         a.Cmain = cin;
         if (!f.use_scale_shift_norm) {        // h = h + emb_out (unet.py:205)
             a.bias_b = film_out + r.film_off;
-            a.bias_b_stride = c->film_total;
+            a.bias_b_stride = film_stride;
         }
         if (r.updown == 1) {
             if (x.size() != 1) { err = "down block with concat input"; return Tens{}; }
@@ -595,7 +644,7 @@ struct Builder {
         d.Cmain = r.cout;
         d.gather = c->g3[lvl_out];
         d.seg_src = Lo.seg();
-        d.gn = GnIn{site2, g2, b2, f.use_scale_shift_norm ? film_out + r.film_off : nullptr, c->film_total, r.cout / 32, 0, 1, (unsigned)c->stats_copy_doubles};
+        d.gn = GnIn{site2, g2, b2, f.use_scale_shift_norm ? film_out + r.film_off : nullptr, film_stride, r.cout / 32, 0, 1, (unsigned)c->stats_copy_doubles};
         if (has_skip_conv) {
             if (r.updown) { err = "up/down block with skip conv"; return Tens{}; }
             d.nskip = (int)x.size();
@@ -712,12 +761,19 @@ struct Builder {
         float* tsin = c->buf("emb.sin", (size_t)f.max_batch * mc);
         float* e0 = c->buf("emb.e0", (size_t)f.max_batch * emb);
         float* e1 = c->buf("emb.e1", (size_t)f.max_batch * emb);
-        film_out = c->buf("emb.film", (size_t)f.max_batch * c->film_total);
         float* W0 = c->wcopy("time_embed.0.weight", {emb, mc});
         float* B0 = c->wcopy("time_embed.0.bias", {emb});
         float* W2 = c->wcopy("time_embed.2.weight", {emb, emb});
         float* B2 = c->wcopy("time_embed.2.bias", {emb});
-        {
+        c->site_parity = mode == MODE_STEP1 ? 1 : 0;
+        if (mode != MODE_FORWARD) {
+            // sampler step: the FiLM row of this step was copied into emb.film_step by the previous step's head
+            // conv (or by k_ddim_init), the statistics arena was zeroed by it, the packed input written by it
+            film_out = c->buf("emb.film_step", (size_t)c->film_total);
+            film_stride = 0;
+        } else {
+            film_out = c->buf("emb.film", (size_t)f.max_batch * c->film_total);
+            film_stride = c->film_total;
             double* st = c->stats;
             const size_t nb = c->stats_bytes;
             push("memset_stats", [st, nb](hipStream_t s) { return hipMemsetAsync(st, 0, nb, s); });
@@ -739,7 +795,7 @@ struct Builder {
         // ---- input assembly (unet.py:1022-1025) ----
         Tens h0;
         h0.lvl = 0; h0.C = 16; h0.p = c->act("h0", 0, 16);
-        {
+        if (mode == MODE_FORWARD) {
             const float *xi = c->xin, *ci = c->condin, *ii = c->icin;
             float* o = h0.p;
             const int Bn = B, L = c->lv[0].L, RR = c->lv[0].b1;
@@ -778,6 +834,10 @@ struct Builder {
             a.out = c->eps; a.out_cm = 1;
             a.nmain = 1; a.src[0] = cur.p; a.C[0] = cur.C; a.Cmain = cur.C; a.gather = c->g3[0]; a.seg_src = L.seg();
             a.gn = GnIn{site, gw, gb, nullptr, 0, cur.C / 32, 0, 1, (unsigned)c->stats_copy_doubles};
+            if (mode != MODE_FORWARD) {             // DDIM update + step hand-over
+                a.ddim = c->d_fuse + (mode == MODE_STEP1 ? 1 : 0);
+                a.step_counter = c->d_counter;
+            }
             add_conv(a, "head", 0);
         }
         if (c->site_cursor > c->n_sites) return fail(MTV_ERR_INVALID, "GN site arena overflow");
@@ -815,13 +875,29 @@ struct Builder {
 
 // Empirical tile selection: every distinct conv shape of the plan is timed once over the valid
 // (MT, NT, NW, KS) candidates with its real arguments (MTV_AUTOTUNE=0 keeps the analytic pick).
+// Tile table.  moditalker_amd/csrc/tune_gfx950.txt (committed, next to the library) holds the measured best tile
+// of every conv shape of the BASELINE configurations, so a fresh process reproduces the same launch plan without
+// timing anything; shapes it does not list are tuned on first use.  MTV_TUNE_CACHE=<file> replaces it (and is
+// appended to: that is how the committed table is regenerated, tools/make_tune_table.sh).
+static std::string default_tune_path() {
+    Dl_info di;
+    if (dladdr((const void*)&default_tune_path, &di) && di.dli_fname) {
+        std::string p(di.dli_fname);
+        const size_t k = p.rfind('/');
+        return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/tune_gfx950.txt";
+    }
+    return "tune_gfx950.txt";
+}
+
 static void tune_cache_load(mtv_ctx* c) {
-    const char* path = getenv("MTV_TUNE_CACHE");
-    if (!path || c->tune_cache_loaded) return;
+    if (c->tune_cache_loaded) return;
     c->tune_cache_loaded = true;
-    if (FILE* f = fopen(path, "r")) {
+    const char* env = getenv("MTV_TUNE_CACHE");
+    const std::string path = env ? std::string(env) : default_tune_path();
+    if (FILE* f = fopen(path.c_str(), "r")) {
         char line[256];
         while (fgets(line, sizeof line, f)) {
+            if (line[0] == '#') continue;
             char* bar = strchr(line, '|');
             if (!bar) continue;
             *bar = 0;
@@ -848,9 +924,17 @@ static int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     const char* env = getenv("MTV_AUTOTUNE");
     if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE")) return MTV_OK;
     static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    struct Events {             // destroyed on every exit path (HIPCHK returns early)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    HIPCHK(hipEventCreate(&ev.e0));
+    HIPCHK(hipEventCreate(&ev.e1));
+    hipEvent_t e0 = ev.e0, e1 = ev.e1;
+    static const int nsamp = []() { const char* e = getenv("MTV_TUNE_SAMPLES"); const int v = e ? atoi(e) : 5; return v < 1 ? 1 : (v > 15 ? 15 : v); }();
     const size_t slab_cap = c->slab_floats[p->B];
     if (!c->flush) {
         c->flush_bytes = (size_t)320 << 20;
@@ -858,7 +942,8 @@ static int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
         if (rcm != MTV_OK) return rcm;
     }
     for (auto& op : p->convs) {
-        const ConvArgs& a = op->a;
+        ConvArgs a = op->a;
+        a.ddim = nullptr;       // the tuner times the conv itself, not the step hand-over
         char key[160];
         snprintf(key, sizeof key, "B%d L%d/%d/%d N%d t%d C%d+%d gn%d f%d r%d s%d cm%d", a.B, a.Lout, a.Lsrc, a.Lskip, a.N, a.ntaps, a.Cmain, a.Cskip,
                  a.gn.sums ? 1 : 0, a.gn.film ? 1 : 0, a.res ? 1 : 0, a.nstat, a.out_cm);
@@ -899,20 +984,22 @@ static int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                             if (conv_smem_bytes(a, t) > 120 * 1024) continue;
                             // cold timing: the caches (32 MB L2 + 256 MB MALL) are flushed before every timed
                             // launch, because in the real step a layer's weights were last touched 0.5 GB ago
-                            float ms_sum = 0.f;
+                            // (median of `nsamp` samples: a single slow sample -- clock ramp, a neighbour's
+                            // traffic -- must not decide the plan)
+                            float samp[16];
                             HIPCHK(launch_conv(a, t, s));
-                            for (int w = 0; w < 3; ++w) {
+                            for (int w = 0; w < nsamp; ++w) {
                                 HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
                                 HIPCHK(hipEventRecord(e0, s));
                                 HIPCHK(launch_conv(a, t, s));
                                 HIPCHK(hipEventRecord(e1, s));
                                 HIPCHK(hipEventSynchronize(e1));
-                                float ms = 0.f;
-                                HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-                                ms_sum += ms;
+                                HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
                             }
-                            if (ms_sum < best_ms) {
-                                best_ms = ms_sum;
+                            std::sort(samp, samp + nsamp);
+                            const float med = samp[nsamp / 2];
+                            if (med < best_ms) {
+                                best_ms = med;
                                 best = t;
                             }
                         }
@@ -925,24 +1012,23 @@ static int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
         op->t = it->second;
         p->ops[op->op_index].name = op->base_name + Builder::conv_tag(op->a, op->t);
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return MTV_OK;
 }
 
-static int get_plan(mtv_ctx* c, int B, Plan** out) {
-    auto it = c->plans.find(B);
+static int get_plan(mtv_ctx* c, int B, int mode, Plan** out) {
+    auto it = c->plans.find({B, mode});
     if (it != c->plans.end()) {
         *out = it->second.get();
         return MTV_OK;
     }
     std::unique_ptr<Plan> p(new Plan());
     p->B = B;
-    Builder b(c, p.get(), B);
+    p->mode = mode;
+    Builder b(c, p.get(), B, mode);
     int rc = b.build();
     if (rc != MTV_OK) return rc;
     *out = p.get();
-    c->plans[B] = std::move(p);
+    c->plans[{B, mode}] = std::move(p);
     return MTV_OK;
 }
 
@@ -1014,7 +1100,7 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
     // statistics arena, staging buffers, sampler state
     c->stats_copy_doubles = (size_t)c->n_sites * cfg->max_batch * 192;
     c->stats_bytes = c->stats_copy_doubles * STAT_COPIES * sizeof(double);
-    if ((rc = c->dmalloc((void**)&c->stats, c->stats_bytes)) != MTV_OK) return rc;
+    if ((rc = c->dmalloc((void**)&c->stats, 2 * c->stats_bytes)) != MTV_OK) return rc;      // one arena per step parity
     const int L = c->lv[0].L, RR = c->lv[0].b1, mb = cfg->max_batch;
     if ((rc = c->dmalloc((void**)&c->xin, (size_t)mb * 4 * L * 4)) != MTV_OK) return rc;
     if ((rc = c->dmalloc((void**)&c->condin, (size_t)mb * 8 * L * 4)) != MTV_OK) return rc;
@@ -1023,6 +1109,8 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
     if ((rc = c->dmalloc((void**)&c->tbuf, (size_t)mb * 8)) != MTV_OK) return rc;
     if ((rc = c->dmalloc((void**)&c->d_counter, 16)) != MTV_OK) return rc;
     HIPCHK(hipMemset(c->d_counter, 0, 16));
+    if ((rc = c->dmalloc((void**)&c->d_fuse, 2 * sizeof(DdimFuse))) != MTV_OK) return rc;
+    HIPCHK(hipMemset(c->d_fuse, 0, 2 * sizeof(DdimFuse)));
     {
         // timestep_embedding frequencies, fp32 like the reference (diffusionmodules.py:118-121)
         const int half = cfg->model_channels / 2;
@@ -1041,24 +1129,18 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
     // build the batch-1 plan now: registers every weight slot and fills the work accounting
     c->accounting = true;
     Plan* p1 = nullptr;
-    rc = get_plan(c.get(), 1, &p1);
+    rc = get_plan(c.get(), 1, MODE_FORWARD, &p1);
     c->accounting = false;
     if (rc != MTV_OK) return rc;
+    Plan* ps = nullptr;
+    if ((rc = get_plan(c.get(), 1, MODE_STEP0, &ps)) != MTV_OK) return rc;
+    c->work.n_launches_step = (int)ps->ops.size();
     *out = c.release();
     return MTV_OK;
 }
 
 int mtv_destroy(mtv_ctx* c) {
-    if (!c) return MTV_OK;
-    (void)hipDeviceSynchronize();
-    for (auto& kv : c->plans) {
-        if (kv.second->g_forward) (void)hipGraphExecDestroy(kv.second->g_forward);
-    }
-    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
-    for (void* p : c->allocs) (void)hipFree(p);
-    if (c->staging) (void)hipFree(c->staging);
-    if (c->d_steps) (void)hipFree(c->d_steps);
-    delete c;
+    delete c;        // ~mtv_ctx binds the context's device, drains it and frees everything
     return MTV_OK;
 }
 
@@ -1172,7 +1254,7 @@ int mtv_forward(mtv_ctx* c, const float* x, const float* cond, const float* imag
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     Plan* p = nullptr;
-    if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
+    if ((rc = get_plan(c, batch, MODE_FORWARD, &p)) != MTV_OK) return rc;
     if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
     if ((rc = stage_inputs(c, x, cond, image_cond, image_cond_len, batch, s)) != MTV_OK) return rc;
     HIPCHK(hipMemcpyAsync(c->tbuf, timesteps, (size_t)batch * 8, hipMemcpyDeviceToDevice, s));
@@ -1186,6 +1268,78 @@ int mtv_forward(mtv_ctx* c, const float* x, const float* cond, const float* imag
     return MTV_OK;
 }
 
+// Sampler set-up shared by mtv_ddim_sample and mtv_profile_step: uploads the step table and the head conv's
+// hand-over records through pinned staging (no stream synchronisation), computes the FiLM row of every step
+// (time-embedding MLP + all emb_layers, unet.py:1011-1012 and :193, batched over the steps), zeroes both statistics
+// arenas, packs the UNet input and resets the step counter.
+static int sampler_setup(mtv_ctx* c, int batch, const float* noise, const mtv_ddim_step* steps, int n_steps, hipStream_t s) {
+    static_assert(sizeof(DdimStep) == sizeof(mtv_ddim_step), "step layout");
+    const int mc = c->cfg.model_channels, emb = c->emb_dim;
+    if (n_steps > c->d_steps_cap) {     // tables grow geometrically; growing does not invalidate captured graphs
+        HIPCHK(hipStreamSynchronize(s)); // (the head conv reaches them through the DdimFuse records, not through kernel args)
+        c->free_step_tables();
+        int cap = 256;
+        while (cap < n_steps) cap *= 2;
+        HIPCHK(hipMalloc((void**)&c->d_steps, (size_t)cap * sizeof(DdimStep)));
+        HIPCHK(hipMalloc((void**)&c->film_tab, (size_t)cap * c->film_total * 4));
+        HIPCHK(hipMalloc((void**)&c->sin_steps, (size_t)cap * mc * 4));
+        HIPCHK(hipMalloc((void**)&c->e0_steps, (size_t)cap * emb * 4));
+        HIPCHK(hipMalloc((void**)&c->e1_steps, (size_t)cap * emb * 4));
+        c->d_steps_cap = cap;
+    }
+    // pinned staging, double buffered: slot k is reused only after the copy issued from it two calls ago has run
+    const size_t need = 2 * sizeof(DdimFuse) + (size_t)n_steps * sizeof(DdimStep);
+    if (need > c->pin_bytes) {
+        HIPCHK(hipStreamSynchronize(s));
+        size_t cap = 64 << 10;
+        while (cap < need) cap *= 2;
+        for (int i = 0; i < 2; ++i) {
+            if (c->h_pin[i]) (void)hipHostFree(c->h_pin[i]);
+            c->h_pin[i] = nullptr;
+            HIPCHK(hipHostMalloc((void**)&c->h_pin[i], cap, hipHostMallocDefault));
+            if (!c->pin_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+        c->pin_bytes = cap;
+    }
+    const int slot = (int)(c->pin_turn++ & 1);
+    HIPCHK(hipEventSynchronize(c->pin_ev[slot]));
+    DdimFuse* hf = reinterpret_cast<DdimFuse*>(c->h_pin[slot]);
+    const size_t arena_floats = c->stats_bytes / 4;
+    for (int par = 0; par < 2; ++par) {
+        DdimFuse f{};
+        f.x = c->xin;
+        f.h0 = c->bufs["act.h0"];
+        f.noise = noise;
+        f.steps = c->d_steps;
+        f.counter = c->d_counter;
+        f.done = c->d_counter + 1;
+        f.n_per_draw = (long long)batch * 4 * c->lv[0].L;
+        f.film_tab = c->film_tab;
+        f.film_out = c->bufs["emb.film_step"];
+        f.film_total = c->film_total;
+        f.n_steps = n_steps;
+        f.zero_arena = reinterpret_cast<float*>(c->stats) + (size_t)(1 - par) * arena_floats;
+        f.zero_vec4 = (long long)(arena_floats / 4);
+        hf[par] = f;
+    }
+    std::memcpy(c->h_pin[slot] + 2 * sizeof(DdimFuse), steps, (size_t)n_steps * sizeof(DdimStep));
+    HIPCHK(hipMemcpyAsync(c->d_fuse, hf, 2 * sizeof(DdimFuse), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_steps, c->h_pin[slot] + 2 * sizeof(DdimFuse), (size_t)n_steps * sizeof(DdimStep), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(c->pin_ev[slot], s));
+    // FiLM rows of all steps: sinusoid -> time_embed.0 -> SiLU -> time_embed.2 -> SiLU -> [all emb_layers]
+    HIPCHK(launch_step_sinusoid(c->d_steps, n_steps, c->freqs, c->sin_steps, mc / 2, s));
+    LinearArgs l0{c->sin_steps, c->bufs["w.time_embed.0.weight"], c->bufs["w.time_embed.0.bias"], c->e0_steps, n_steps, mc, emb, emb, 0};
+    HIPCHK(launch_linear_rows(l0, s));
+    LinearArgs l2{c->e0_steps, c->bufs["w.time_embed.2.weight"], c->bufs["w.time_embed.2.bias"], c->e1_steps, n_steps, emb, emb, emb, 1};
+    HIPCHK(launch_linear_rows(l2, s));
+    LinearArgs lf{c->e1_steps, c->bufs["w.film"], c->bufs["w.film_bias"], c->film_tab, n_steps, emb, c->film_total, c->film_total, 1};
+    HIPCHK(launch_linear_rows(lf, s));
+    HIPCHK(hipMemsetAsync(c->stats, 0, 2 * c->stats_bytes, s));
+    HIPCHK(launch_pack_input(c->xin, c->condin, c->icin, c->lv[0].b1, c->bufs["act.h0"], batch, c->lv[0].L, c->lv[0].b1, s));
+    HIPCHK(launch_ddim_init(c->d_fuse, s));
+    return MTV_OK;
+}
+
 int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* image_cond, int image_cond_len,
                     const float* noise, int n_noise, const mtv_ddim_step* steps, int n_steps, int batch, void* stream) {
     int rc = check_ready(c, batch);
@@ -1195,53 +1349,39 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
     for (int i = 0; i < n_steps; ++i) {
         if (steps[i].noise_index >= n_noise) return fail(MTV_ERR_INVALID, "noise_index out of range");
         if (steps[i].noise_index >= 0 && !noise) return fail(MTV_ERR_INVALID, "noise required");
+        if (steps[i].t < 0) return fail(MTV_ERR_INVALID, "negative timestep");
     }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
-    Plan* p = nullptr;
-    if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
-    if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
-    // device-resident step table (grown geometrically; growing invalidates captured step graphs)
-    if (n_steps > c->d_steps_cap) {
-        HIPCHK(hipStreamSynchronize(s));
-        if (c->d_steps) (void)hipFree(c->d_steps);
-        c->d_steps = nullptr;
-        int cap = 256;
-        while (cap < n_steps) cap *= 2;
-        HIPCHK(hipMalloc((void**)&c->d_steps, (size_t)cap * sizeof(DdimStep)));
-        c->d_steps_cap = cap;
+    Plan* p[2] = {nullptr, nullptr};
+    for (int par = 0; par < 2; ++par) {
+        if ((rc = get_plan(c, batch, par ? MODE_STEP1 : MODE_STEP0, &p[par])) != MTV_OK) return rc;
+        if ((rc = autotune(c, p[par], s)) != MTV_OK) return rc;
     }
-    static_assert(sizeof(DdimStep) == sizeof(mtv_ddim_step), "step layout");
-    // mark the end of the table so the advance kernel never reads t past n_steps
-    std::vector<DdimStep> host((const DdimStep*)steps, (const DdimStep*)steps + n_steps);
-    HIPCHK(hipMemcpyAsync(c->d_steps, host.data(), (size_t)n_steps * sizeof(DdimStep), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));   // `host` is pageable and dies at return
     if ((rc = stage_inputs(c, x_io, cond, image_cond, image_cond_len, batch, s)) != MTV_OK) return rc;
-    HIPCHK(launch_ddim_init(c->d_steps, c->d_counter, c->tbuf, batch, s));
-    const int64_t n = (int64_t)batch * 4 * c->lv[0].L;
+    if ((rc = sampler_setup(c, batch, noise, steps, n_steps, s)) != MTV_OK) return rc;
+    // the loop: ONE graph replay per step (even / odd steps alternate between the two statistics arenas); the
+    // step index, its coefficients, its FiLM row and its noise slab are all resolved on the device
     for (int i = 0; i < n_steps; ++i) {
-        // forward part: graph replay (or eager); tail: plain launches (noise pointer is a call argument)
+        Plan* q = p[i & 1];
         if (c->eager) {
-            if ((rc = run_ops(c, p, s)) != MTV_OK) return rc;
+            if ((rc = run_ops(c, q, s)) != MTV_OK) return rc;
         } else {
-            if (!p->g_forward && (rc = capture(c, p, &p->g_forward)) != MTV_OK) return rc;
-            HIPCHK(hipGraphLaunch(p->g_forward, s));
+            if (!q->g_forward && (rc = capture(c, q, &q->g_forward)) != MTV_OK) return rc;
+            HIPCHK(hipGraphLaunch(q->g_forward, s));
         }
-        HIPCHK(launch_ddim_update(c->xin, c->eps, noise, c->d_steps, c->d_counter, n, n, s));
-        HIPCHK(launch_ddim_advance(c->d_steps, c->d_counter, n_steps, c->tbuf, batch, s));
     }
-    HIPCHK(hipMemcpyAsync(x_io, c->xin, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(x_io, c->xin, (size_t)batch * 4 * c->lv[0].L * 4, hipMemcpyDeviceToDevice, s));
     return MTV_OK;
 }
 
-int mtv_profile_forward(mtv_ctx* c, int batch, int iters, mtv_op_time* out, int cap, int* n_out, void* stream) {
+static int profile_plan(mtv_ctx* c, int batch, int mode, int iters, mtv_op_time* out, int cap, int* n_out, hipStream_t s) {
     int rc = check_ready(c, batch);
     if (rc != MTV_OK) return rc;
     if (iters < 1 || !n_out) return fail(MTV_ERR_INVALID, "bad argument");
-    hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     Plan* p = nullptr;
-    if ((rc = get_plan(c, batch, &p)) != MTV_OK) return rc;
+    if ((rc = get_plan(c, batch, mode, &p)) != MTV_OK) return rc;
     if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
     const int n = (int)p->ops.size();
     *n_out = n;
@@ -1252,7 +1392,9 @@ int mtv_profile_forward(mtv_ctx* c, int batch, int iters, mtv_op_time* out, int 
     std::vector<hipEvent_t> ev((size_t)n + 1);
     for (auto& e : ev) HIPCHK(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
+    const mtv_ddim_step one{500, 0, 1.0f, 0.0f, 1.0f, 0.0f, 0.0f, -1};    // a 1-entry step table for the step plan
     for (int it = 0; it < iters; ++it) {
+        if (mode != MODE_FORWARD && (rc = sampler_setup(c, batch, nullptr, &one, 1, s)) != MTV_OK) return rc;
         HIPCHK(hipEventRecord(ev[0], s));
         for (int i = 0; i < n; ++i) {
             hipError_t e = p->ops[i].run(s);
@@ -1274,6 +1416,48 @@ int mtv_profile_forward(mtv_ctx* c, int batch, int iters, mtv_op_time* out, int 
         out[i].flops = p->ops[i].flops;
         out[i].bytes = p->ops[i].bytes;
     }
+    return MTV_OK;
+}
+
+int mtv_profile_forward(mtv_ctx* c, int batch, int iters, mtv_op_time* out, int cap, int* n_out, void* stream) {
+    return profile_plan(c, batch, MODE_FORWARD, iters, out, cap, n_out, (hipStream_t)stream);
+}
+
+int mtv_profile_step(mtv_ctx* c, int batch, int iters, mtv_op_time* out, int cap, int* n_out, void* stream) {
+    return profile_plan(c, batch, MODE_STEP0, iters, out, cap, n_out, (hipStream_t)stream);
+}
+
+// Diagnostic (needs the -DMTV_ABLATE=64 build of conv.hip and MTV_STAMPS=1 in the environment at plan-build time):
+// runs one sampler step with plain launches, in plan order like the real chain, and writes the in-kernel phase
+// timestamps (s_memtime ticks) of four sampled workgroups of every conv to `path`.
+int mtv_debug_stamps(mtv_ctx* c, int batch, const char* path, void* stream) {
+    int rc = check_ready(c, batch);
+    if (rc != MTV_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(c->device));
+    Plan* p = nullptr;
+    if ((rc = get_plan(c, batch, MODE_STEP0, &p)) != MTV_OK) return rc;
+    if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
+    const mtv_ddim_step one{500, 0, 1.0f, 0.0f, 1.0f, 0.0f, 0.0f, -1};
+    for (int it = 0; it < 3; ++it) {
+        if ((rc = sampler_setup(c, batch, nullptr, &one, 1, s)) != MTV_OK) return rc;
+        for (auto& op : p->convs)
+            if (op->a.dbg) HIPCHK(hipMemsetAsync(op->a.dbg, 0, 256, s));
+        if ((rc = run_ops(c, p, s)) != MTV_OK) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    FILE* f = fopen(path, "w");
+    if (!f) return fail(MTV_ERR_INVALID, "cannot open stamp file");
+    fprintf(f, "# per conv: name, then 4 sampled blocks (first, second, middle, last) x stamps[0..7]: 7=entry 0=decoded 1=ring issued 2=prologue done 3=K loop done 4=reduced 5=epilogue stored 6=statistics done (0 = path not taken)\n");
+    for (auto& op : p->convs) {
+        if (!op->a.dbg) continue;
+        unsigned long long h[32];
+        HIPCHK(hipMemcpy(h, op->a.dbg, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(f, "%s", p->ops[op->op_index].name.c_str());
+        for (int i = 0; i < 32; ++i) fprintf(f, " %llu", h[i]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
     return MTV_OK;
 }
 

@@ -270,18 +270,20 @@ class UNetModel(nn.Module):
         _lib.check(_lib.load().mtv_get_work(ctx, C.byref(w)), "mtv_get_work")
         return {f: getattr(w, f) for f, _ in w._fields_}
 
-    def profile_forward(self, batch: int = 1, iters: int = 5, device=None):
-        """Per-launch hipEvent timings of one forward (plain launches): list of dicts
-        {name, ms, flops, bytes}.  Inputs are whatever the staging buffers currently hold."""
+    def profile_forward(self, batch: int = 1, iters: int = 5, device=None, step: bool = False):
+        """Per-launch hipEvent timings (plain launches) of one forward -- or, with step=True, of one SAMPLER STEP
+        (the launch sequence DDPM.sample replays: UNet launches only, DDIM update inside the head conv): list of
+        dicts {name, ms, flops, bytes}.  Inputs are whatever the staging buffers currently hold."""
         dev = torch.device(device) if device is not None else next(self.parameters()).device
         ctx = self.hip_context(dev, batch)
         lib = _lib.load()
+        fn, what = (lib.mtv_profile_step, "mtv_profile_step") if step else (lib.mtv_profile_forward, "mtv_profile_forward")
         n = C.c_int()
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.mtv_profile_forward(ctx, batch, iters, None, 0, C.byref(n), stream), "mtv_profile_forward")
-        table = (_lib.MtvOpTime * n.value)()
         with torch.cuda.device(dev):
-            _lib.check(lib.mtv_profile_forward(ctx, batch, iters, table, n.value, C.byref(n), stream), "mtv_profile_forward")
+            _lib.check(fn(ctx, batch, iters, None, 0, C.byref(n), stream), what)
+            table = (_lib.MtvOpTime * n.value)()
+            _lib.check(fn(ctx, batch, iters, table, n.value, C.byref(n), stream), what)
         return [dict(name=t.name.decode(), ms=float(t.ms), flops=float(t.flops), bytes=float(t.bytes)) for t in table]
 
     # ------------------------------------------------------------------ reference-shaped API

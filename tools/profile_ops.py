@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-launch table of one base-config UNet forward (hipEvent timing around plain launches):
+"""Per-launch table of one base-config sampler step (or, --forward, one UNet forward); hipEvent timing around plain launches:
 name [shape, tile], us, TFLOP/s, algorithmic GB/s.  Usage: python tools/profile_ops.py [--batch B] [--iters N]"""
 import argparse
 import os
@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--res", type=int, default=32)
 ap.add_argument("--frames", type=int, default=16)
+ap.add_argument("--forward", action="store_true", help="profile UNetModel.forward's launches instead of one sampler step's")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = dict(BASE_UNET_CONFIG, image_size=args.res)
@@ -28,8 +29,8 @@ cond = torch.rand(B, 8, L, device=dev) * 2 - 1
 ic = torch.rand(B, 4, R * R, device=dev) * 2 - 1
 net(x, cond, ic, torch.full((B,), 500, device=dev))
 um = net.diffusion_model
-um.profile_forward(B, 2)
-prof = um.profile_forward(B, args.iters)
+um.profile_forward(B, 2, step=not args.forward)
+prof = um.profile_forward(B, args.iters, step=not args.forward)
 tot = sum(p["ms"] for p in prof)
 print(f"# {len(prof)} launches, sum {tot:.3f} ms")
 for p in prof:
