@@ -152,6 +152,39 @@ int mtv_selftest_geometry(int res, int frames, int n_levels);
  * nearest x2 upsample.  Returns -1 for zero padding, else source_token | plane << 28. */
 int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up);
 
+/* ------------------------------------------------------------------------------------------------
+ * The autoencoder steps either side of the denoising loop.
+ * Replaces ViTAutoencoder.decode_from_sample / .extract (MToV/models/autoencoder/autoencoder_vit.py:257-275, 212-255;
+ * called at MToV/sample.py:328-332,369,386).  A separate context of the same opaque type: weights go in through
+ * mtv_num_weights / mtv_weight_info / mtv_load_weight / mtv_weights_missing with the reference's state_dict keys
+ * (e.g. "decoder.layers.0.0.fn.to_qkv.weight" [1536,384], "to_pixel.1.weight" [384,3,8,8]).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mtv_ae_config {
+    int32_t channels;      /* ddconfig.channels (384)                                                    */
+    int32_t resolution;    /* ddconfig.resolution (256)                                                  */
+    int32_t frames;        /* ddconfig.timesteps / splits (16)                                           */
+    int32_t patch;         /* 8 (4 at resolution 128: autoencoder_vit.py:105-107)                        */
+    int32_t embed_dim;     /* 4                                                                          */
+    int32_t depth;         /* 8 TimeSformer layers per coder (autoencoder_vit.py:110-116)                */
+    int32_t heads;         /* 8                                                                          */
+    int32_t dim_head;      /* 64                                                                         */
+    int32_t max_batch;
+} mtv_ae_config;
+
+int mtv_ae_create(const mtv_ae_config* cfg, mtv_ctx** out);
+int mtv_ae_destroy(mtv_ctx* ctx);
+/* Rotary tables, computed by the host exactly as RotaryEmbedding / AxialRotaryEmbedding.forward do
+ * (vit_modules.py:29-49,57-62): time_tab [frames][2][dim_head], space_tab [(res/patch)^2][2][dim_head]; row 0 = sin,
+ * row 1 = cos.  Host or device pointers. */
+int mtv_ae_set_rotary(mtv_ctx* ctx, const float* time_tab, const float* space_tab);
+/* latents [B, embed_dim, r*r + 2*frames*r] (r = resolution/patch; the sampler's output) -> frames
+ * [B*frames, 3, resolution, resolution] in (-1, 1).  Device pointers. */
+int mtv_ae_decode(mtv_ctx* ctx, const float* latents, float* frames_out, int batch, void* stream);
+/* video [B, 3, frames, resolution, resolution] in [-1, 1] -> latents [B, embed_dim, r*r + 2*frames*r] (tanh outputs). */
+int mtv_ae_extract(mtv_ctx* ctx, const float* video, float* latents_out, int batch, void* stream);
+/* Per-launch hipEvent timing of decode (extract != 0: of extract), like mtv_profile_forward. */
+int mtv_ae_profile(mtv_ctx* ctx, int batch, int extract, int iters, mtv_op_time* out, int cap, int* n_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,83 +40,38 @@ __device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgc
 
 __device__ __forceinline__ int seg_of(const SegInfo& s, int tok) { return tok >= s.b2 ? 2 : (tok >= s.b1 ? 1 : 0); }
 
-// K walk.  K is cut into SEGMENTS = (tap, source part) pairs -- the tapped parts for every tap, then
-// the parts of the fused 1x1 skip conv -- and each segment into chunks of 16 channels.  The segment
-// descriptors are built once per workgroup in LDS; a Cursor keeps the wave-uniform state in SGPRs
-// (forced with readfirstlane: the compiler cannot prove uniformity of anything derived from the wave
-// id) and the per-lane row offsets in VGPRs.  Advancing inside a segment is two scalar pointer bumps.
+// K walk.  K is cut into chunks of 16 channels, ordered tap by tap over the tapped source part(s), then over the
+// parts of the fused 1x1 skip conv.  Every workgroup first writes one 16-byte RECORD per chunk of its K range into
+// LDS (all threads, one chunk each: source pointer, W row, coefficient channel, row stride, tap), so that a wave's
+// walk is branch-free: chunk n -> read record n (one broadcast ds_read_b128), read the tap's row table, issue the
+// loads.  (The previous design walked (tap, part) segments with a scalar cursor; its set-up and segment changes
+// cost ~1000 straight-line instructions per wave before the first load -- at two waves per SIMD that was 2.5-4.6 us
+// of every launch; measured with the phase stamps, tools/stamps.py.)
 #ifndef MTV_ABLATE
 #define MTV_ABLATE 0          // tools/ubench/conv_bench builds ablated variants: 1 no MFMA, 2 no A loads, 4 no B loads,
                               // 8 no transform, 16 prologue only, 32 no reduction/epilogue
 #endif
 
-struct SegDesc {              // 32 bytes, one per segment, in LDS
-    unsigned src_lo, src_hi;  // base pointer of the source part
-    int Cp;                   // channels of the part
-    int Ls;                   // tokens per batch element of the source
-    int crow;                 // W row of channel 0 of this segment
-    int coff;                 // concat channel of channel 0 (coefficient index)
-    int tap;                  // row of the index table (== ntaps for skip segments)
-    int skip;
+struct ChunkRec {             // 16 bytes, one per K chunk of the workgroup, in LDS
+    unsigned a_lo, a_hi;      // source part base + 4 * (first channel of the chunk)
+    unsigned wrow;            // W row of the chunk's first channel
+    unsigned meta;            // coefficient channel (16 bits) | channels of the part / 16 (8 bits) << 16 | tap (4 bits) << 24 | skip << 28
 };
 
 __device__ __forceinline__ int usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// exact n / d for 0 <= n < 2^22, d > 0, given inv = 1.0f / d: a float multiply and a +-1 correction instead of the
+// ~40-instruction integer division sequence (these divisions sit on every wave's critical path before its first load)
+__device__ __forceinline__ int fdiv(int n, int d, float inv) { return FDiv{inv}(n, d); }
+
 #if MTV_ABLATE & 64   // phase timestamps of thread 0 of four sampled blocks (first two, middle, last) -> a.dbg (conv_bench, MTV_STAMPS)
 #define MTV_STAMP(k) do { if (threadIdx.x == 0 && a.dbg) { const int sb_ = blockIdx.x < 2 ? (int)blockIdx.x : (blockIdx.x == gridDim.x / 2 ? 2 : (blockIdx.x == gridDim.x - 1 ? 3 : -1)); \
-                          if (sb_ >= 0) a.dbg[sb_ * 8 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+                          if (sb_ >= 0) a.dbg[sb_ * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define MTV_STAMP(k) do { } while (0)
 #endif
 
 typedef __attribute__((address_space(1))) const char gchar;   // global (not flat) loads: vmcnt only, saddr addressing
-
-template <int MT>
-struct Cursor {
-    int seg, c, cend, coff, skip;      // uniform
-    gchar* abase;                      // uniform: part base + c * 4
-    gchar* wbase;                      // uniform: W + (crow + c) * ldw * 4
-    unsigned rowoff[MT];               // per lane: ((b * Ls + st) * Cp + 4q) * 4
-    int e[MT];                         // per lane: index-table entries of this lane's rows for this tap
-};
-
-// uniform half of entering a segment (needs only the segment table): everything the W loads need
-template <int MT>
-__device__ __forceinline__ void enter_segment_u(Cursor<MT>& k, const SegDesc* segs, const float* W, int ldw, int c) {
-    const SegDesc* d = segs + k.seg;
-    const unsigned lo = (unsigned)usgpr((int)d->src_lo), hi = (unsigned)usgpr((int)d->src_hi);
-    const int Cp = usgpr(d->Cp), crow = usgpr(d->crow);
-    k.coff = usgpr(d->coff);
-    k.skip = usgpr(d->skip);
-    k.c = c;
-    k.cend = Cp;
-    gchar* sp = (gchar*)(((unsigned long long)hi << 32) | lo);
-    k.abase = sp + (size_t)c * 4;
-    k.wbase = (gchar*)(unsigned long long)W + (size_t)(crow + c) * (size_t)ldw * 4;
-}
-
-// per-lane half: byte offsets of this lane's A rows for the segment's tap.  Normally read from the LDS
-// index table; `ident` (no gather tables at all: 1x1 convs) derives them from the token index, which
-// needs no memory at all -- such convs start their A loads before the prologue.
-template <int MT>
-__device__ __forceinline__ void enter_segment_rows(Cursor<MT>& k, const SegDesc* segs, const int* idx, int rows, int b, int i, int q,
-                                                   bool ident, int tok0, int Lout, const SegInfo& sgi) {
-    const SegDesc* d = segs + k.seg;
-    const int Cp = usgpr(d->Cp), Ls = usgpr(d->Ls), tap = usgpr(d->tap);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int e;
-        if (ident) {
-            const int tok = tok0 + 16 * mt + i;
-            e = tok < Lout ? (k.skip ? tok : (tok | (seg_of(sgi, tok) << 28))) : -1;
-        } else {
-            e = idx[tap * rows + 16 * mt + i];
-        }
-        k.e[mt] = e;
-        const unsigned st = e < 0 ? 0u : (unsigned)(e & 0x0FFFFFFF);   // padded rows read a valid address, zeroed later
-        k.rowoff[mt] = (((unsigned)b * (unsigned)Ls + st) * (unsigned)Cp + 4u * q) * 4u;
-    }
-}
 
 template <int MT, int NT>
 struct Raw {
@@ -126,13 +81,32 @@ struct Raw {
     int cc, skip;     // uniform: coefficient channel of this chunk, skip flag
 };
 
-template <int MT, int NT>
-__device__ __forceinline__ void load_b(const Cursor<MT>& k, unsigned woff, unsigned ldw4, Raw<MT, NT>& o) {
-    o.cc = k.coff + k.c;
-    o.skip = k.skip;
+// what a wave needs to turn a chunk record into loads (all uniform except woff / q16 / i)
+struct WalkCtx {
+    const ChunkRec* recs;     // LDS, indexed by chunk - wg_ch0
+    const int* idx;           // LDS row table [(ntaps + 1)][ROWS]: source token | plane << 28, or -1 (zero pad)
+    int wg_ch0;
+    unsigned bL[2];           // b * Lsrc, b * Lskip
+    gchar* W;
+    unsigned ldw4;            // bytes per W row
+    unsigned woff;            // per lane: ((4q) * ldw + n0 + NT * i) * 4
+    unsigned q16;             // per lane: 16 * q (bytes)
+    int i;
+};
+
+template <int MT, int NT, int ROWS>
+__device__ __forceinline__ void load_chunk(const WalkCtx& w, int ch, Raw<MT, NT>& o) {
+    const ChunkRec* rp = w.recs + (ch - w.wg_ch0);
+    const unsigned a_lo = (unsigned)usgpr((int)rp->a_lo), a_hi = (unsigned)usgpr((int)rp->a_hi);
+    const unsigned wrow = (unsigned)usgpr((int)rp->wrow), meta = (unsigned)usgpr((int)rp->meta);
+    const int tap = (int)((meta >> 24) & 15u), skip = (int)(meta >> 28);
+    const unsigned Cp4 = ((meta >> 16) & 0xFFu) << 6;            // bytes per source row of this part
+    o.cc = (int)(meta & 0xFFFFu);
+    o.skip = skip;
+    gchar* wbase = w.W + (size_t)wrow * (size_t)w.ldw4;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        gchar* p = k.wbase + (woff + (unsigned)s * ldw4);
+        gchar* p = wbase + (w.woff + (unsigned)s * w.ldw4);
         if constexpr (MTV_ABLATE & 4) {
 #pragma unroll
             for (int nb = 0; nb < NT; ++nb) o.b[s][nb] = 0.5f;
@@ -146,22 +120,17 @@ __device__ __forceinline__ void load_b(const Cursor<MT>& k, unsigned woff, unsig
             o.b[s][0] = *(const __attribute__((address_space(1))) float*)p;
         }
     }
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void load_a(const Cursor<MT>& k, Raw<MT, NT>& o) {
+    gchar* abase = (gchar*)(((unsigned long long)a_hi << 32) | a_lo);
+    const unsigned bl = skip ? w.bL[1] : w.bL[0];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        o.e[mt] = k.e[mt];
+        const int e = w.idx[tap * ROWS + 16 * mt + w.i];
+        o.e[mt] = e;
+        const unsigned st = e < 0 ? 0u : (unsigned)(e & 0x0FFFFFFF);   // padded rows read a valid address, zeroed later
+        const unsigned rowoff = (bl + st) * Cp4 + w.q16;
         if constexpr (MTV_ABLATE & 2) o.a[mt] = f32x4{1.f, 2.f, 3.f, 4.f};
-        else o.a[mt] = *(const __attribute__((address_space(1))) f32x4*)(k.abase + k.rowoff[mt]);
+        else o.a[mt] = *(const __attribute__((address_space(1))) f32x4*)(abase + rowoff);
     }
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void load_chunk(const Cursor<MT>& k, unsigned woff, unsigned ldw4, Raw<MT, NT>& o) {
-    load_b<MT, NT>(k, woff, ldw4, o);
-    load_a<MT, NT>(k, o);
 }
 
 // coef holds, per (plane, channel), the folded affine {A, B}: y = x*A + B with A = gn_scale*(1+film_scale),
@@ -208,7 +177,7 @@ __device__ __forceinline__ float epi(const ConvArgs& a, float v, int b, int tok,
 
 __device__ __forceinline__ void stat_add(const ConvArgs& a, int b, int sg, int n, double s, double ss) {
     for (int t = 0; t < a.nstat; ++t) {
-        const int g = (a.stat[t].coff + n) / a.stat[t].gs;
+        const int g = fdiv(a.stat[t].coff + n, a.stat[t].gs, a.stat[t].inv_gs);
         double* dst = a.stat[t].sums + (size_t)(blockIdx.x & (STAT_COPIES - 1)) * a.stat_cstride + (((size_t)b * 3 + sg) * 32 + g) * 2;
         atomicAdd(dst, s);
         atomicAdd(dst + 1, ss);
@@ -226,9 +195,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // SGPR: the K walk is scalar
     const int i = lane & 15, q = lane >> 4;
     constexpr int ROWS = 16 * MT, COLS = 16 * NT, NTH = NW * 64;
-    const int tiles_per_b = (a.Lout + ROWS - 1) / ROWS;
+    const int tiles_per_b = a.tiles_per_b, tiles_n = a.tiles_n;       // (launch_conv precomputes the tiling and the
+                                                                       // reciprocals the decode below divides by)
     // ---- sampler-step head (mtv_internal.h DdimFuse): the hand-over record and the step index are requested at
-    // entry and used once this workgroup's operand ring is in flight (head_duties below), so their latency is hidden
+    // entry and used once this workgroup's operand ring is in flight, so their latency is hidden
     const DdimFuse* dd = a.ddim;
     DdimFuse ddv{};
     int step_now = 0;
@@ -240,139 +210,152 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     // the 8 XCDs (private L2s).  xmap 0: row tiles vary fastest (every L2 sees the whole -- small -- weight
     // matrix).  xmap 1, for weight-dominated layers: workgroup id % 8 selects the (column tile, K slice)
     // class, so each weight slice is fetched from HBM by exactly ONE L2 (speed only, never correctness).
-    const int tiles_n = (a.N + COLS - 1) / COLS;
-    const int Bt = a.B * tiles_per_b;
     int bx, by, bz;
-    if (a.xmap == 0) {
-        bx = blockIdx.x % Bt;
-        const int rest = blockIdx.x / Bt;
-        by = rest % tiles_n;
-        bz = rest / tiles_n;
-    } else {
-        const int S = tiles_n * a.KS, Sx = (S + 7) >> 3;
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int sl = xcd + 8 * (j % Sx);
-        if (sl >= S) return;                       // padding block (whole workgroup, before any barrier)
-        bx = j / Sx;
-        by = sl % tiles_n;
-        bz = sl / tiles_n;
+    {
+        const int blk = usgpr((int)blockIdx.x);
+        if (a.xmap == 0) {
+            const int rest = fdiv(blk, a.Bt, a.inv_Bt);
+            bx = blk - rest * a.Bt;
+            bz = fdiv(rest, tiles_n, a.inv_tiles_n);
+            by = rest - bz * tiles_n;
+        } else {
+            const int xcd = blk & 7, j = blk >> 3;
+            bx = fdiv(j, a.Sx, a.inv_Sx);
+            const int sl = xcd + 8 * (j - bx * a.Sx);
+            if (sl >= tiles_n * a.KS) return;          // padding block (whole workgroup, before any barrier)
+            bz = fdiv(sl, tiles_n, a.inv_tiles_n);
+            by = sl - bz * tiles_n;
+        }
+        bx = usgpr(bx); by = usgpr(by); bz = usgpr(bz);
     }
-    const int b = bx / tiles_per_b;
+    const int b = usgpr(fdiv(bx, tiles_per_b, a.inv_tiles_per_b));
     const int tok0 = (bx - b * tiles_per_b) * ROWS;
     const int n0 = by * COLS;
     const int Cmain = a.Cmain;
     const bool do_gn = a.gn.sums != nullptr;
 
-    MTV_STAMP(0);
-    // ---- LDS: segment descriptors, source-token table [(ntaps+1)][ROWS], folded per-(plane, channel) affine {A, B}
-    constexpr int MAXSEG = 24;
-    SegDesc* segs = reinterpret_cast<SegDesc*>(smem);
-    int* idx = reinterpret_cast<int*>(smem + MAXSEG * 8);
-    const int idx_floats = ((a.ntaps + 1) * ROWS + 3) & ~3;
-    float2* coef = reinterpret_cast<float2*>(smem + MAXSEG * 8 + idx_floats);
-    const int nseg_main = a.ntaps * a.nmain, nseg = nseg_main + a.nskip;
-    if (tid < nseg) {
-        const bool skip = tid >= nseg_main;
-        const int local = skip ? tid - nseg_main : tid;
-        const int nparts = skip ? a.nskip : a.nmain;
-        const int tap = skip ? a.ntaps : (nparts > 1 ? local >> 1 : local);
-        const bool second = nparts > 1 && (local & 1);
-        const float* sp = skip ? (second ? a.src[3] : a.src[2]) : (second ? a.src[1] : a.src[0]);
-        SegDesc d;
-        d.src_lo = (unsigned)(reinterpret_cast<unsigned long long>(sp) & 0xFFFFFFFFull);
-        d.src_hi = (unsigned)(reinterpret_cast<unsigned long long>(sp) >> 32);
-        d.Cp = skip ? (second ? a.C[3] : a.C[2]) : (second ? a.C[1] : a.C[0]);
-        d.Ls = skip ? a.Lskip : a.Lsrc;
-        d.coff = second ? (skip ? a.C[2] : a.C[0]) : 0;
-        d.crow = (skip ? a.ntaps * Cmain : tap * Cmain) + d.coff;
-        d.tap = tap;
-        d.skip = skip ? 1 : 0;
-        segs[tid] = d;
+    // GroupNorm inputs are requested FIRST (they are needed last, after the operand ring is issued): the statistics of
+    // the producer(s) -- (plane, group) sums over the privatised copies, 8 independent 16-byte loads per thread -- and this
+    // thread's first 4 channels of gamma / beta / FiLM.  Their round trip overlaps the table build and the ring issue.
+    constexpr int PER = 4;                          // channels per thread per round (one 16-byte load per operand)
+    f32x4 ga, be, s1, sh;
+    const float* film = (do_gn && a.gn.film) ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
+    auto fetch = [&](int c0) {                      // (Cmain % 16 == 0 and every table is 16-byte aligned)
+        ga = *reinterpret_cast<const f32x4*>(a.gn.gamma + c0);
+        be = *reinterpret_cast<const f32x4*>(a.gn.beta + c0);
+        s1 = f32x4{1.f, 1.f, 1.f, 1.f};
+        sh = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (film) {
+            s1 += *reinterpret_cast<const f32x4*>(film + c0);
+            sh = *reinterpret_cast<const f32x4*>(film + Cmain + c0);
+        }
+    };
+    // (the 8 copies stay in registers un-summed until the ring is issued -- adding them here would wait for them here;
+    // the largest tiles have no registers to spare and sum at once)
+    constexpr bool HOLD = MT * NT <= 8 && NW < 16;
+    f64x2 v0 = {0.0, 0.0};
+    f64x2 vraw[HOLD ? STAT_COPIES : 1];
+    if (do_gn) {
+        if (tid * PER < Cmain) fetch(tid * PER);
+        if (tid < 96) {
+#pragma unroll
+            for (int k = 0; k < STAT_COPIES; ++k) {
+                const f64x2 t = *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)tid * 2);
+                if constexpr (HOLD) vraw[k] = t;
+                else v0 += t;
+            }
+        }
     }
-    // source-token table.  Identity / arithmetic gathers need no memory, so the table is complete before the
-    // first barrier and the operand ring can start right away; table gathers are fetched during the prologue.
-    const bool ident = a.gather == nullptr && a.gather_skip == nullptr;
-    const bool no_tab = (a.gather == nullptr || a.geo_main != 0) && (a.gather_skip == nullptr || a.geo_skip != 0);
+
+    MTV_STAMP(0);
+    // ---- LDS: chunk records of this workgroup's K range | source-token table [(ntaps+1)][ROWS] | folded
+    // per-(plane, channel) affine {A, B}
+    const int slice0 = bz * NW;                                        // this workgroup's K slices: slice0 .. slice0 + NW - 1
+    const int wg_ch0 = slice0 * a.cps_q + min(slice0, a.cps_r);        // slice s covers chunks [s*q + min(s, r), +q (+1 if s < r))
+    const int wg_ch1 = (slice0 + NW) * a.cps_q + min(slice0 + NW, a.cps_r);
+    ChunkRec* recs = reinterpret_cast<ChunkRec*>(smem);
+    int* idx = reinterpret_cast<int*>(smem + a.rec_cap * 4);
+    const int idx_floats = ((a.ntaps + 1) * ROWS + 3) & ~3;
+    float2* coef = reinterpret_cast<float2*>(smem + a.rec_cap * 4 + idx_floats);
+    {
+        const int nmainch = a.ntaps * a.cpt;
+        for (int e = tid; e < wg_ch1 - wg_ch0; e += NTH) {
+            const int ch = wg_ch0 + e;
+            const bool skip = ch >= nmainch;
+            const int tap = skip ? a.ntaps : fdiv(ch, a.cpt, a.inv_cpt);
+            const int w = skip ? ch - nmainch : ch - tap * a.cpt;
+            const int c0_16 = (skip ? a.C[2] : a.C[0]) >> 4;
+            const bool second = w >= c0_16;                            // second part of a channel concatenation
+            const int c = (second ? w - c0_16 : w) << 4;
+            const float* sp = skip ? (second ? a.src[3] : a.src[2]) : (second ? a.src[1] : a.src[0]);
+            const int Cp = skip ? (second ? a.C[3] : a.C[2]) : (second ? a.C[1] : a.C[0]);
+            const int coff = second ? (skip ? a.C[2] : a.C[0]) : 0;
+            const unsigned long long ab = reinterpret_cast<unsigned long long>(sp) + (unsigned long long)c * 4ull;
+            ChunkRec r;
+            r.a_lo = (unsigned)(ab & 0xFFFFFFFFull);
+            r.a_hi = (unsigned)(ab >> 32);
+            r.wrow = (unsigned)((skip ? a.ntaps * Cmain : tap * Cmain) + coff + c);
+            r.meta = (unsigned)(coff + c) | ((unsigned)(Cp >> 4) << 16) | ((unsigned)tap << 24) | ((unsigned)(skip ? 1 : 0) << 28);
+            recs[e] = r;
+        }
+    }
+    // source-token table: identity, arithmetic (geo_source) or -- only if the host check of the formula ever failed
+    // -- the gather tables in global memory.  Complete before the first barrier, so every wave's operand ring starts
+    // right after it.
     auto skip_src = [&](int tok) -> int {
-        if (a.geo_skip) return geo_source(a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF;
+        if (a.geo_skip) return geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF;
         return a.gather_skip ? a.gather_skip[tok] : tok;
     };
-    auto build_idx = [&]() {
-        for (int e = tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
-            const int t = e / ROWS, r = e - t * ROWS;
-            const int tok = tok0 + r;
-            int v = -1;
-            if (tok < a.Lout) {
-                if (t < a.ntaps) {
-                    if (a.geo_main) {
-                        const int ky = t / 3;
-                        v = geo_source(a.geo_r, a.geo_t, tok, ky, t - 3 * ky, a.geo_main == 2);
-                    } else {
-                        const int st = a.gather ? a.gather[t * a.Lout + tok] : tok;
-                        v = st < 0 ? -1 : (st | (seg_of(a.seg_src, st) << 28));
-                    }
+    for (int e = tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
+        const int t = e / ROWS, r = e - t * ROWS;
+        const int tok = tok0 + r;
+        int v = -1;
+        if (tok < a.Lout) {
+            if (t < a.ntaps) {
+                if (a.geo_main) {
+                    const int ky = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
+                    v = geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, ky, t - 3 * ky, a.geo_main == 2);
                 } else {
-                    v = skip_src(tok);
+                    const int st = a.gather ? a.gather[t * a.Lout + tok] : tok;
+                    v = st < 0 ? -1 : (st | (seg_of(a.seg_src, st) << 28));
                 }
+            } else {
+                v = skip_src(tok);
             }
-            idx[e] = v;
         }
-    };
-    if (no_tab && !ident) build_idx();
+        idx[e] = v;
+    }
+    MTV_STAMP(8);
     __syncthreads();
+    MTV_STAMP(9);
 
-    // ---- this wave's chunk range; the W fragment of its first chunk is requested NOW, so the (HBM-cold)
-    // weight latency overlaps the rest of the prologue
-    const int nchunks = a.ntaps * (Cmain >> 4) + (a.Cskip >> 4);
-    const int slice = bz * NW + wave, nslices = a.KS * NW;
-    const int ch0 = usgpr((int)(((unsigned)nchunks * (unsigned)slice) / (unsigned)nslices));
-    const int ch1 = usgpr((int)(((unsigned)nchunks * (unsigned)(slice + 1)) / (unsigned)nslices));
-    const int ldw = a.ldw;
-    const float* Wp = a.W;
-    const unsigned ldw4 = (unsigned)ldw * 4u;
-    const unsigned woff = (4u * q * (unsigned)ldw + (unsigned)(n0 + NT * i)) * 4u;
+    // ---- this wave's chunk range; its whole operand ring (A and W) is requested NOW, so the (HBM-cold) weight
+    // latency overlaps the rest of the prologue
+    const int slice = slice0 + wave;
+    const int ch0 = slice * a.cps_q + min(slice, a.cps_r);
+    const int ch1 = ch0 + a.cps_q + (slice < a.cps_r ? 1 : 0);
+    WalkCtx wc;
+    wc.recs = recs;
+    wc.idx = idx;
+    wc.wg_ch0 = wg_ch0;
+    wc.bL[0] = (unsigned)b * (unsigned)a.Lsrc;
+    wc.bL[1] = (unsigned)b * (unsigned)a.Lskip;
+    wc.W = (gchar*)(unsigned long long)a.W;
+    wc.ldw4 = (unsigned)a.ldw * 4u;
+    wc.woff = (4u * q * (unsigned)a.ldw + (unsigned)(n0 + NT * i)) * 4u;
+    wc.q16 = 16u * q;
+    wc.i = i;
     // chunks in flight per wave, bounded by the register budget (1024-thread blocks get 128 VGPRs)
     constexpr int DEPTH = NW == 16 ? (MT * NT >= 4 ? 2 : (MT * NT >= 2 ? 3 : 4)) : (MT * NT >= 16 ? 2 : (MT * NT >= 8 ? 3 : 4));
-    Cursor<MT> cur;
     Raw<MT, NT> ring[DEPTH];
-    const int Lout_ = a.Lout;
-    const SegInfo sgi = a.seg_src;
-    auto advance = [&]() {
-        cur.c += 16;
-        if (cur.c < cur.cend) {
-            cur.abase += 64;
-            cur.wbase += (size_t)64 * (size_t)ldw;
-        } else {
-            cur.seg += 1;
-            enter_segment_u<MT>(cur, segs, Wp, ldw, 0);
-            enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, ident, tok0, Lout_, sgi);
-        }
-    };
-    auto fill_ring = [&]() {                 // slots 1..DEPTH-1 (slot 0 is loaded separately)
+    int nx = ch0;                                       // next chunk to request
 #pragma unroll
-        for (int d = 1; d < DEPTH; ++d)
-            if (d < ch1 - ch0) {
-                advance();
-                load_chunk<MT, NT>(cur, woff, ldw4, ring[d]);
-            }
-    };
-    if (ch0 < ch1) {
-        int seg = 0, left = ch0;
-        while (seg + 1 < nseg) {
-            const int cp16 = usgpr(segs[seg].Cp) >> 4;
-            if (left < cp16) break;
-            left -= cp16;
-            ++seg;
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < ch1 - ch0) {
+            load_chunk<MT, NT, ROWS>(wc, nx, ring[d]);
+            ++nx;
+            if (d == 0) MTV_STAMP(10);
         }
-        cur.seg = seg;
-        enter_segment_u<MT>(cur, segs, Wp, ldw, left << 4);
-        load_b<MT, NT>(cur, woff, ldw4, ring[0]);
-        if (no_tab) {                        // the index table (if any) is ready: the whole ring starts now
-            enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, ident, tok0, Lout_, sgi);
-            load_a<MT, NT>(cur, ring[0]);
-            fill_ring();
-        }
-    }
 
     DdimStep stp{};
     if (dd) {
@@ -388,32 +371,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         stp = ddv.steps[step_now];
     }
     MTV_STAMP(1);
-    if (!no_tab) build_idx();
     if (do_gn) {
-        // per-channel inputs of the first round are requested BEFORE the statistics are reduced, so
-        // the two global-memory latencies overlap
-        constexpr int PER = 4;                          // channels per thread per round
-        float ga[PER], be[PER], s1[PER], sh[PER];
-        const float* film = a.gn.film ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
-        auto fetch = [&](int c0) {
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                ga[k] = a.gn.gamma[c0 + k];
-                be[k] = a.gn.beta[c0 + k];
-                s1[k] = film ? 1.0f + film[c0 + k] : 1.0f;
-                sh[k] = film ? film[Cmain + c0 + k] : 0.0f;
-            }
-        };
-        if (tid * PER < Cmain) fetch(tid * PER);
-        // (plane, group) sums over the privatised copies: 8 independent 16-byte loads per thread, all in flight
-        // together.  A cross-plane site (AttentionBlock1D) adds its three planes up through LDS afterwards --
-        // summing 24 entries per thread in registers made the compiler serialise the loads.
+        // A cross-plane site (AttentionBlock1D) adds its three planes up through LDS -- summing 24 entries per thread
+        // in registers made the compiler serialise the loads.
         const bool whole = a.gn.whole != 0;
-        f64x2 v0 = {0.0, 0.0};
-        if (tid < 96) {
+        if constexpr (HOLD) {
+            if (tid < 96) {
 #pragma unroll
-            for (int k = 0; k < STAT_COPIES; ++k)
-                v0 += *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)tid * 2);
+                for (int k = 0; k < STAT_COPIES; ++k) v0 += vraw[k];
+            }
         }
         if constexpr (NTH < 96) {                       // one-wave workgroups: entries 64..95 in a second round
             if (tid < 32) {
@@ -432,28 +398,30 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         for (int e = tid; e < 96; e += NTH) {
             const int sg = e >> 5, g = e & 31;
             f64x2 v;
-            double n;
+            double inv_n;                               // 1 / (tokens of the plane (or of all planes) x channels per group), from the host
             if (whole) {
                 v = (s_dp[g] + s_dp[32 + g]) + s_dp[64 + g];
-                n = (double)a.seg_src.L * a.gn.gs;
+                inv_n = a.gn.inv_n[3];
             } else {
                 v = NTH < 96 ? s_dp[e] : v0;
-                const int len = sg == 0 ? a.seg_src.b1 : (sg == 1 ? a.seg_src.b2 - a.seg_src.b1 : a.seg_src.L - a.seg_src.b2);
-                n = (double)len * a.gn.gs;
+                inv_n = a.gn.inv_n[sg];
             }
-            const double mean = v[0] / n;
-            double var = v[1] / n - mean * mean;
+            const double mean = v[0] * inv_n;
+            double var = v[1] * inv_n - mean * mean;
             var = var < 0.0 ? 0.0 : var;
             s_mr[sg][g] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));   // fp64 only where cancellation bites
         }
         __syncthreads();
         for (int c0 = tid * PER; c0 < Cmain; c0 += NTH * PER) {
             if (c0 != tid * PER) fetch(c0);
+            int grp[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) grp[k] = fdiv(c0 + k, a.gn.gs, a.gn.inv_gs);
 #pragma unroll
             for (int sg = 0; sg < 3; ++sg)
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
-                    const float2 mr = s_mr[sg][(c0 + k) / a.gn.gs];
+                    const float2 mr = s_mr[sg][grp[k]];
                     const float sc = mr.y * ga[k];
                     const float bi = be[k] - sc * mr.x;
                     coef[sg * Cmain + c0 + k] = make_float2(sc * s1[k], fmaf(bi, s1[k], sh[k]));
@@ -486,27 +454,22 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             if (a.bias2) pre_bias += *reinterpret_cast<const f32x4*>(a.bias2 + n);
             if (a.bias_b) pre_bias += *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + n);
             if (a.res) {
-                const int rs = skip_src(tok);
+                const int rs = idx[a.ntaps * ROWS + rr];            // skip/residual source row of this output row
                 pre_res = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + rs) * a.N + n);
             }
         }
     }
 
     if (ch0 < ch1) {
-        if (!no_tab) {
-            enter_segment_rows<MT>(cur, segs, idx, ROWS, b, i, q, false, tok0, Lout_, sgi);
-            load_a<MT, NT>(cur, ring[0]);
-            fill_ring();
-        }
-        // ring of DEPTH chunks in flight.  Steady state has no conditionals, so every ring slot keeps
+        // ring of DEPTH chunks in flight.  The walk has no conditionals (chunk records), so every ring slot keeps
         // fixed registers and the loads of the next DEPTH-1 chunks stay in flight under the MFMAs.
-        int n = ch1 - ch0;                       // chunks not yet multiplied (ring slot 0 holds the first)
+        int n = ch1 - ch0;                       // chunks not yet multiplied
         while (n >= 2 * DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, ring[d], acc);
-                advance();
-                load_chunk<MT, NT>(cur, woff, ldw4, ring[d]);
+                load_chunk<MT, NT, ROWS>(wc, nx, ring[d]);
+                ++nx;
             }
             n -= DEPTH;
         }
@@ -516,8 +479,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             if (d < n) {
                 mma_chunk<MT, NT>(coef, Cmain, do_gn, act, q, ring[d], acc);
                 if (d + DEPTH < n) {
-                    advance();
-                    load_chunk<MT, NT>(cur, woff, ldw4, ring[d]);
+                    load_chunk<MT, NT, ROWS>(wc, nx, ring[d]);
+                    ++nx;
                 }
             }
 #pragma unroll
@@ -529,6 +492,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     // ---- fixed-order tree over the NW waves (lane-linear LDS image: conflict-free), LDS reused
     __syncthreads();
     float* red = smem;
+    // per-(plane, channel quad) statistics slots of this tile: their own LDS region past everything else (a.qs_off),
+    // zeroed here, filled by LDS fp64 atomics from the epilogue pass below
+    double* qs = reinterpret_cast<double*>(smem + a.qs_off);     // [3 planes][QPR quads][2]
+    bool fast = a.nstat > 0 && (a.N & 3) == 0;
+    for (int t = 0; t < a.nstat; ++t) fast = fast && ((a.stat[t].gs & 3) == 0);
+    if (fast)
+        for (int e = tid; e < 3 * (COLS / 4) * 2; e += NTH) qs[e] = 0.0;
     constexpr int TILE_REGS = MT * NT * 4;
     constexpr int LDR = COLS + 4;
     constexpr bool ONE_STAGE = NW > 1 && NW * TILE_REGS * 64 * 4 <= 48 * 1024;   // all partials fit in LDS at once
@@ -686,7 +656,18 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
                 else a.out[((size_t)b * a.Lout + tok) * a.N + n + k] = v[k];
             }
         }
-        if (want_stats) *reinterpret_cast<f32x4*>(fin + rr * LDR + cq * 4) = v;
+        if (fast) {
+            // GroupNorm statistics of the output for its consumers: (sum, sum of squares) of this quad in fp64, added to
+            // the tile's (plane, quad) slot in LDS (lanes of a wave-instruction hold different quads of <= 4 rows: at
+            // most a 4-way same-address serialisation); combined per group after the pass
+            const int sgq = seg_of(a.seg_out, tok);
+            const double sq = ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+            const double ssq = ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+            atomicAdd(&qs[(sgq * QPR + cq) * 2], sq);
+            atomicAdd(&qs[(sgq * QPR + cq) * 2 + 1], ssq);
+        } else if (want_stats) {
+            *reinterpret_cast<f32x4*>(fin + rr * LDR + cq * 4) = v;
+        }
     }
     MTV_STAMP(5);
     if (dd) {
@@ -702,45 +683,24 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     }
     if (!want_stats) return;
 
-    // ---- pass 2 (column-major over the tile): GroupNorm statistics of the output for its consumers.
-    // Rows are reduced with wave shuffles, the channel quads of one group are then combined in LDS, so a
-    // workgroup issues ONE atomic pair per (plane, group, consumer) -- the per-address atomic rate is what
-    // bounds this epilogue (measured: quads of a wide group hitting one address cost 5x the whole kernel).
+    // ---- statistics hand-over.  A workgroup issues ONE fp64 atomic pair per (plane, group, consumer) -- the
+    // per-address atomic rate is what bounds this epilogue (measured: quads of a wide group hitting one address cost
+    // 5x the whole kernel) -- into copy blockIdx & 7 of the consumer site's table.
     __syncthreads();
-    constexpr int W = ROWS < 64 ? ROWS : 64;         // lanes that share one channel quad
-    double* qs = reinterpret_cast<double*>(fin + ROWS * LDR);   // [3 planes][QPR quads][2]
-    bool fast = true;
-    for (int t = 0; t < a.nstat; ++t) fast = fast && ((a.stat[t].gs & 3) == 0);
-    if (fast) {
-        for (int e = tid; e < 3 * QPR * 2; e += NTH) qs[e] = 0.0;
-        __syncthreads();
-    }
-    for (int base = 0; base < QUADS; base += NTH) {
-        const int e = base + tid;
-        const int cq = e / ROWS, rr = e - cq * ROWS;
-        const int tok = tok0 + rr, n = n0 + cq * 4;
-        const bool ok = e < QUADS && tok < a.Lout && n < a.N;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(fin + rr * LDR + cq * 4);
-        const int sg = ok ? seg_of(a.seg_out, tok) : -1;
-        for (int sgi = 0; sgi < 3; ++sgi) {
-            if (!__any(sg == sgi)) continue;
-            const bool mine = sg == sgi;
-            if (fast) {
-                double s = mine ? ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]) : 0.0;
-                double ss = mine ? ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]) : 0.0;
-#pragma unroll
-                for (int o = W / 2; o >= 1; o >>= 1) {
-                    s += __shfl_xor(s, o);
-                    ss += __shfl_xor(ss, o);
-                }
-                // W == 64: one wave per quad (exclusive slot).  W < 64: several waves may hold rows of the
-                // same quad only when ROWS > 64, which never happens (ROWS <= 64) -> exclusive as well.
-                if ((lane & (W - 1)) == 0 && e < QUADS && n < a.N) {
-                    qs[(sgi * QPR + cq) * 2] = s;
-                    qs[(sgi * QPR + cq) * 2 + 1] = ss;
-                }
-            } else {
+    if (!fast) {
+        // groups narrower than a channel quad (test-size models only): per-channel sums, rows reduced by wave shuffles
+        constexpr int W = ROWS < 64 ? ROWS : 64;         // lanes that share one channel quad
+        for (int base = 0; base < QUADS; base += NTH) {
+            const int e = base + tid;
+            const int cq = e / ROWS, rr = e - cq * ROWS;
+            const int tok = tok0 + rr, n = n0 + cq * 4;
+            const bool ok = e < QUADS && tok < a.Lout && n < a.N;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(fin + rr * LDR + cq * 4);
+            const int sg = ok ? seg_of(a.seg_out, tok) : -1;
+            for (int sgi = 0; sgi < 3; ++sgi) {
+                if (!__any(sg == sgi)) continue;
+                const bool mine = sg == sgi;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     double s = mine ? (double)v[k] : 0.0;
@@ -754,9 +714,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
                 }
             }
         }
+        return;
     }
-    if (!fast) return;
-    __syncthreads();
     // one thread per (consumer, plane, quad): the first quad of each group inside this tile adds up its group
     for (int e = tid; e < a.nstat * 3 * QPR; e += NTH) {
         const int t = e / (3 * QPR), r2 = e - t * 3 * QPR;
@@ -764,10 +723,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         const int n = n0 + cq * 4;
         if (n >= a.N) continue;
         const int gs = a.stat[t].gs, coff = a.stat[t].coff;
-        const int g = (coff + n) / gs;
-        if (cq > 0 && (coff + n - 4) / gs == g) continue;           // not the first quad of its group in this tile
+        const float inv_gs = a.stat[t].inv_gs;
+        const int g = fdiv(coff + n, gs, inv_gs);
+        if (cq > 0 && fdiv(coff + n - 4, gs, inv_gs) == g) continue;           // not the first quad of its group in this tile
+        const int qend = min(QPR, min((a.N - n0 + 3) >> 2, ((g + 1) * gs - coff - n0 + 3) >> 2));   // quads of group g inside this tile
         double s = 0.0, ss = 0.0;
-        for (int c2 = cq; c2 < QPR && n0 + c2 * 4 < a.N && (coff + n0 + c2 * 4) / gs == g; ++c2) {
+        for (int c2 = cq; c2 < qend; ++c2) {
             s += qs[(sgi * QPR + c2) * 2];
             ss += qs[(sgi * QPR + c2) * 2 + 1];
         }
@@ -783,17 +744,28 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
 // --------------------------------------------------------------------------------------------
 // tile / split selection: a small analytic cost model (times in microseconds)
 // --------------------------------------------------------------------------------------------
-static size_t lds_bytes(int MT, int NT, int NW, int ntaps, int Cmain, bool has_gn) {
+// chunk records a workgroup needs room for: its NW slices of ceil-ish nchunks / (KS * NW) chunks each
+static int rec_capacity(int nchunks, int NW, int KS) {
+    const int ns = NW * KS, q = nchunks / ns, r = nchunks % ns;
+    return (NW * q + (NW < r ? NW : r) + 3) & ~3;
+}
+
+// LDS layout: [chunk records | row table | coefficients] during the K loop, reused by [wave partials | finished tile]
+// afterwards; the per-quad statistics slots sit past both (qs_off, in floats).  Returns the total in bytes.
+static size_t lds_bytes(int MT, int NT, int NW, int KS, int ntaps, int Cmain, int Cskip, bool has_gn, int* qs_off = nullptr) {
     const int ROWS = 16 * MT, COLS = 16 * NT;
-    const size_t idx = (size_t)(((ntaps + 1) * ROWS + 3) & ~3) * 4 + 24 * 32;   // + segment descriptors
+    const int nchunks = ntaps * (Cmain / 16) + Cskip / 16;
+    const size_t idx = (size_t)(((ntaps + 1) * ROWS + 3) & ~3) * 4 + (size_t)rec_capacity(nchunks, NW, KS) * 16;
     const size_t coef = has_gn ? (size_t)24 * Cmain : 0;
     const size_t part = (size_t)MT * NT * 4 * 64 * 4;                 // one wave's partial tile
-    const size_t fin = (size_t)ROWS * (COLS + 4) * 4 + 3 * (COLS / 4) * 2 * 8;   // finished tile + per-quad statistics
+    const size_t fin = (size_t)ROWS * (COLS + 4) * 4;                 // finished tile
     const bool one_stage = NW > 1 && NW * part <= 48 * 1024;
     const size_t redu = one_stage ? NW * part + fin : ((size_t)(NW / 2) * part > fin ? (size_t)(NW / 2) * part : fin);
     size_t r = idx + coef;
     if (redu > r) r = redu;
-    return r;
+    r = (r + 15) & ~(size_t)15;
+    if (qs_off) *qs_off = (int)(r / 4);
+    return r + (size_t)3 * (COLS / 4) * 2 * 8;                       // + per-(plane, quad) statistics
 }
 
 ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn) {
@@ -827,7 +799,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
         if (MT > 1 && 16 * (MT / 2) >= Lout) continue;             // tile taller than needed
         const double tiles = (double)B * ((Lout + 16 * MT - 1) / (16 * MT)) * ((N + 16 * NT - 1) / (16 * NT));
         for (int NW = 1; NW <= 16; NW *= 2) {
-            if (lds_bytes(MT, NT, NW, ntaps_guess, Cmain, has_gn) > 96 * 1024) continue;
+            if (lds_bytes(MT, NT, NW, 1, ntaps_guess, Cmain, 0, has_gn) > 96 * 1024) continue;
             if (NW == 16 && MT * NT >= 8) continue;                   // 1024-thread blocks cap VGPRs at 128: these spill
             for (int KS = 1; KS <= 16; KS *= 2) {
                 const int slices = NW * KS;
@@ -854,16 +826,34 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
 }
 
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
-    return lds_bytes(t.MT, t.NT, t.NW, a.ntaps, a.Cmain, a.gn.sums != nullptr);
+    return lds_bytes(t.MT, t.NT, t.NW, t.KS, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
 }
 
 template <int MT, int NT, int NW>
-static hipError_t launch_conv_t(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_conv_t(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
     const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT);
     const int tiles_n = (a.N + 16 * NT - 1) / (16 * NT);
     const long nblk = a.xmap ? 8L * ((tiles_n * a.KS + 7) / 8) * a.B * tiles : (long)a.B * tiles * tiles_n * a.KS;
+    if (nblk >= (1L << 21)) return hipErrorInvalidValue;         // (the kernel's float-reciprocal decode is exact below 2^22)
+    // everything the kernel would otherwise divide for
+    const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16, ns = NW * a.KS;
+    a.tiles_per_b = tiles;
+    a.tiles_n = tiles_n;
+    a.Bt = a.B * tiles;
+    a.Sx = (tiles_n * a.KS + 7) / 8;
+    a.inv_tiles_per_b = 1.0f / (float)tiles;
+    a.inv_tiles_n = 1.0f / (float)tiles_n;
+    a.inv_Bt = 1.0f / (float)a.Bt;
+    a.inv_Sx = 1.0f / (float)a.Sx;
+    a.cpt = a.Cmain / 16;
+    a.inv_cpt = 1.0f / (float)a.cpt;
+    a.geo_inv_r = a.geo_r > 0 ? 1.0f / (float)a.geo_r : 0.f;
+    a.cps_q = nchunks / ns;
+    a.cps_r = nchunks % ns;
+    a.rec_cap = rec_capacity(nchunks, NW, a.KS);
     dim3 grid((unsigned)nblk);
-    const size_t smem = conv_smem_bytes(a, ConvTile{MT, NT, NW, a.KS, 0});
+    const size_t smem = lds_bytes(MT, NT, NW, a.KS, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr, &a.qs_off);
     hipLaunchKernelGGL((k_conv<MT, NT, NW>), grid, dim3(NW * 64), smem, s, a);
     return hipGetLastError();
 }

@@ -206,10 +206,18 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     const int rest = blockIdx.x / a.H;
     const int nblk = a.blk_prefix[a.nseg];
     const int qblk = rest % nblk, b = rest / nblk;
-    int sg = 0;
-    while (sg + 1 < a.nseg && qblk >= a.blk_prefix[sg + 1]) ++sg;
-    const int q0 = (qblk - a.blk_prefix[sg]) * (16 * QW) + qw * 16;
-    const int start = a.seg_start[sg], len = a.seg_len[sg];
+    int sg = 0, q0, start, len;
+    if (a.seg_uniform) {                            // equal segments: segment = qblk / blocks per segment
+        sg = qblk / a.bps;
+        len = a.seg_uniform;
+        start = sg * len;
+        q0 = (qblk - sg * a.bps) * (16 * QW) + qw * 16;
+    } else {
+        while (sg + 1 < a.nseg && qblk >= a.blk_prefix[sg + 1]) ++sg;
+        q0 = (qblk - a.blk_prefix[sg]) * (16 * QW) + qw * 16;
+        start = a.seg_start[sg];
+        len = a.seg_len[sg];
+    }
     const int RS = 3 * a.C;
     const float* base = a.qkv + (size_t)b * a.L * RS + (size_t)h * 3 * D;
     const float scale = a.scale;
@@ -392,11 +400,20 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     //   long segments : 4 x 2 (8 waves, 2 per SIMD: one wave's softmax VALU overlaps the other's MFMAs)
     //   short segments: 1 x 4 -- there are too few query tiles to fill 256 CUs, so the keys are split instead
     long blocks64 = 0;
-    for (int i = 0; i < a.nseg; ++i) blocks64 += (a.seg_len[i] + 63) / 64;
-    const bool wide = blocks64 * a.H * a.B >= 256 || d >= 128;
+    const int nuni = a.seg_uniform ? a.L / a.seg_uniform : 0;
+    if (a.seg_uniform) blocks64 = (long)nuni * ((a.seg_uniform + 63) / 64);
+    else
+        for (int i = 0; i < a.nseg; ++i) blocks64 += (a.seg_len[i] + 63) / 64;
+    const bool wide = (blocks64 * a.H * a.B >= 256 && (!a.seg_uniform || a.seg_uniform >= 64)) || d >= 128;
     const int qw = wide ? 4 : 1;
     a.blk_prefix[0] = 0;
-    for (int i = 0; i < a.nseg; ++i) a.blk_prefix[i + 1] = a.blk_prefix[i] + (a.seg_len[i] + 16 * qw - 1) / (16 * qw);
+    if (a.seg_uniform) {
+        a.nseg = 1;
+        a.bps = (a.seg_uniform + 16 * qw - 1) / (16 * qw);
+        a.blk_prefix[1] = nuni * a.bps;
+    } else {
+        for (int i = 0; i < a.nseg; ++i) a.blk_prefix[i + 1] = a.blk_prefix[i] + (a.seg_len[i] + 16 * qw - 1) / (16 * qw);
+    }
     dim3 grid((unsigned)(a.blk_prefix[a.nseg] * a.H * a.B));
     static int wide_ksp = -1;                       // tuning aid: MTV_ATT_KSP=2|4 (key parts of the 4-tile shape)
     if (wide_ksp < 0) {
@@ -412,6 +429,7 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
         case 8: MTV_ATT(8, 4, 4); break;
         case 16: MTV_ATT(16, 4, 4); break;
         case 32: MTV_ATT(32, 4, 4); break;
+        case 48: MTV_ATT(48, 4, 4); break;      // the autoencoder's quant stacks (autoencoder_vit.py:140-142: dim_head = 384/8)
         case 64: MTV_ATT(64, 2, 2); break;
         case 128: hipLaunchKernelGGL((k_attention<128, 4, 1>), grid, dim3(256), 0, s, a); break;
         default: return hipErrorInvalidValue;

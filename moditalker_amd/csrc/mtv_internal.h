@@ -24,6 +24,9 @@ struct GnIn {
     int whole;            // 1: statistics over all L tokens (AttentionBlock1D); 0: per plane
     int act;              // 1: SiLU after the affine
     unsigned cstride;     // doubles between the privatised copies of the statistics arena
+    // filled by add_conv from the fields above (the kernel multiplies instead of dividing):
+    float inv_gs;         // 1 / gs
+    double inv_n[4];      // 1 / (tokens x gs) of plane 0, 1, 2 and of all planes together (`whole`)
 };
 
 // Producer-side GroupNorm statistics: a conv epilogue adds the (sum, sumsq) of its output to the
@@ -37,6 +40,7 @@ struct StatOut {
     double* sums;   // copy 0 of [B][3][32][2]
     int gs;         // consumer's channels per group
     int coff;
+    float inv_gs;   // 1 / gs
 };
 
 struct DdimStep;
@@ -97,6 +101,14 @@ struct ConvArgs {
     // 2 = 3x3 taps on the nearest-x2-upsampled source.  geo_skip: 0 = `gather_skip` table / identity,
     // 2 = nearest-x2-upsampled source.  (geo_r, geo_t) = output-level plane geometry.
     int geo_main, geo_skip, geo_r, geo_t;
+    // ---- derived by launch_conv() from the tile (the kernel never divides by a run-time value on its way to the
+    // first load: these are the quotients / reciprocals it needs)
+    int tiles_per_b, tiles_n, Bt, Sx;      // row tiles per batch element, column tiles, B * tiles_per_b, ceil(tiles_n * KS / 8)
+    float inv_tiles_per_b, inv_tiles_n, inv_Bt, inv_Sx, inv_cpt, geo_inv_r;
+    int cpt;                               // K chunks (16 channels) per tap = Cmain / 16
+    int cps_q, cps_r;                      // chunks per K slice: slice s of KS * NW covers [s*q + min(s, r), + q + (s < r))
+    int rec_cap;                           // chunk records per workgroup (LDS capacity, 16 bytes each)
+    int qs_off;                            // LDS offset (floats) of the per-quad statistics slots
     const DdimFuse* ddim;    // sampler-step head only (nullptr otherwise)
     const int* step_counter; // ... the device-side step index (DdimFuse::counter; here too so it is loaded at entry)
     unsigned long long* dbg; // phase timestamps for tools/ubench/conv_bench (nullptr in the product)
@@ -137,11 +149,17 @@ __device__ __forceinline__ void touch_kernargs() {
 // Source token of (tap ky,kx in 0..2; output token) on the tri-plane grid of a level with planes
 // xy r x r | yt t x r | xt t x r; `up`: the source lives on the (r/2, t/2) level (nearest x2 upsample).
 // Returns -1 for zero padding, else token | plane << 28 (the layout of the kernel's index table).
-__host__ __device__ inline int geo_source(int r, int t, int tok, int ky, int kx, bool up) {
+// `Div`: how local / r is evaluated -- plain integer division on the host (the checker of mtv_create and the CPU tests),
+// the exact float-reciprocal form inside the kernels (FDiv below); everything else is the same code.
+struct IDiv {
+    __host__ __device__ int operator()(int n, int d) const { return n / d; }
+};
+template <class Div>
+__host__ __device__ inline int geo_source_t(Div dv, int r, int t, int tok, int ky, int kx, bool up) {
     const int b1 = r * r, b2 = b1 + t * r;
     const int p = tok >= b2 ? 2 : (tok >= b1 ? 1 : 0);
     const int off = p == 0 ? 0 : (p == 1 ? b1 : b2), h = p == 0 ? r : t;
-    const int local = tok - off, y = local / r, x = local - y * r;
+    const int local = tok - off, y = dv(local, r), x = local - y * r;
     const int yy = y + ky - 1, xx = x + kx - 1;
     if (yy < 0 || yy >= h || xx < 0 || xx >= r) return -1;
     if (!up) return (off + yy * r + xx) | (p << 28);
@@ -149,6 +167,17 @@ __host__ __device__ inline int geo_source(int r, int t, int tok, int ky, int kx,
     const int offs = p == 0 ? 0 : (p == 1 ? b1s : b2s);
     return (offs + (yy >> 1) * rs + (xx >> 1)) | (p << 28);
 }
+__host__ __device__ inline int geo_source(int r, int t, int tok, int ky, int kx, bool up) { return geo_source_t(IDiv{}, r, t, tok, ky, kx, up); }
+#if defined(__HIPCC__)
+struct FDiv {      // exact n / d for 0 <= n < 2^22 given inv = 1.0f / d (one multiply and a +-1 correction)
+    float inv;
+    __device__ __forceinline__ int operator()(int n, int d) const {
+        int qt = (int)(((float)n + 0.5f) * inv);
+        const int r = n - qt * d;
+        return qt + (r >= d) - (r < 0);
+    }
+};
+#endif
 
 struct StatsArgs {   // (fallback pass: writes copy 0 only)
     const float* src[2];
@@ -181,6 +210,10 @@ struct AttnArgs {
     int seg_start[3], seg_len[3];
     int blk_prefix[4];       // prefix sums of ceil(seg_len/64): one workgroup per 64 queries
     float scale;             // d^-1/4, applied to q AND k (unet.py:322-323)
+    // uniform segmentation (the autoencoder's time / space attention: thousands of equal segments): when
+    // seg_uniform > 0 the token axis is cut into L / seg_uniform segments of that length and seg_start/len are unused
+    int seg_uniform;
+    int bps;                 // query blocks per uniform segment (set by launch_attention)
 };
 
 struct LinearArgs {
@@ -228,5 +261,8 @@ hipError_t launch_step_sinusoid(const DdimStep* steps, int n_steps, const float*
 hipError_t launch_linear_rows(const LinearArgs& a, hipStream_t s);   // k_linear for many rows: W read once per 8 rows
 hipError_t launch_ddim_init(const DdimFuse* f, hipStream_t s);
 hipError_t launch_repack_conv(const float* src, float* dst, int N, int C, int ntaps, int ld, hipStream_t s);
+// ---- autoencoder kernels (ae.hip) ----
+hipError_t launch_repack_qkv(const float* src, float* dst, int H, int d, int C, int ld, hipStream_t s);
+hipError_t launch_repeat(const float* src, float* dst, int n, int rep, hipStream_t s);
 
 }  // namespace mtv

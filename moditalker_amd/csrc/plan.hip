@@ -5,226 +5,13 @@
 // the plan is MI355X-first: one token-major channels-last buffer per activation, planes batched in
 // every launch, skip concatenations expressed as two-source K loops, timestep FiLM for all
 // ResBlocks in one GEMV, the whole step replayed as one hipGraph with a device-side step counter.
-#include <dlfcn.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <memory>
-#include <string>
-#include <vector>
-
-#include "../../include/mtv_hip.h"
-#include "mtv_internal.h"
-
-using namespace mtv;
+#include "plan_internal.h"
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
+int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e__ = (expr);                                                                       \
-        if (e__ != hipSuccess)                                                                         \
-            return fail(MTV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));              \
-    } while (0)
-
-namespace {
-
-struct Level {
-    int r, t, L, b1, b2;
-    SegInfo seg() const { return SegInfo{b1, b2, L}; }
-};
-
-enum Role { ROLE_COPY = 0, ROLE_CONV = 1 };
-
-struct WSlot {
-    std::string key;
-    std::vector<int64_t> shape;
-    Role role;
-    float* dst;
-    int ld;         // ROLE_CONV: leading dimension (padded output channels)
-    bool loaded;
-};
-
-struct Tens {
-    float* p = nullptr;
-    int C = 0;
-    int lvl = 0;
-};
-
-struct ResDesc {
-    int cin, cout, updown;   // updown: 0 none, 1 down, 2 up
-    int film_off;
-};
-struct Layer {
-    int type;                // 0 stem conv, 1 resblock, 2 attention (2-D, per plane)
-    ResDesc res;
-    int c;
-    std::string pre;
-};
-struct Stage {
-    std::vector<Layer> layers;
-    int attn1_c = 0;         // channels of the cross-plane AttentionBlock1D after the stage (0: Identity)
-    std::string attn1_pre;
-    std::string tap;
-};
-
-struct Op {
-    std::function<hipError_t(hipStream_t)> run;
-    std::string name;
-    double flops = 0.0;    // algorithmic FLOPs of this launch (at the plan's batch size)
-    double bytes = 0.0;    // algorithmic HBM bytes: weights once + activations in/out once
-};
-
-struct ConvOp {                 // one convolution of the plan; args/tile are patched after creation
-    ConvArgs a;                 // (statistics targets, slab, auto-tuned tile), so launches read them late
-    ConvTile t;
-    std::string base_name;
-    int op_index = -1;
-};
-
-// A plan is built per (batch size, mode).  FORWARD: one UNetModel.forward for arbitrary per-clip timesteps
-// (time-embedding chain + input packing + UNet -> eps).  STEP0 / STEP1: one denoising step of the sampler, UNet
-// launches ONLY -- FiLM rows come from a per-call table, the sample is packed by the previous step's head conv,
-// the DDIM update runs in the head conv's epilogue; the two differ in the GroupNorm statistics arena they use
-// (a step's head zeroes the other parity's arena, so no memset launch either).
-enum Mode { MODE_FORWARD = 0, MODE_STEP0 = 1, MODE_STEP1 = 2 };
-
-struct Plan {
-    int B = 0;
-    int mode = MODE_FORWARD;
-    std::vector<std::shared_ptr<ConvOp>> convs;
-    bool tuned = false;
-    std::vector<Op> ops;           // UNet forward
-    hipGraphExec_t g_forward = nullptr;
-};
-
-}  // namespace
-
-struct mtv_ctx {
-    mtv_config cfg{};
-    int device = 0;
-    std::vector<Level> lv;
-    std::vector<Stage> inputs, outputs;
-    Stage middle;
-    int film_total = 0;
-    int n_sites = 0;
-    int emb_dim = 0;
-
-    std::vector<WSlot> slots;
-    std::map<std::string, int> slot_index;
-    std::map<std::string, float*> bufs;         // named activation / weight buffers
-    std::map<std::string, std::pair<int, int>> taps;   // tap name -> (level, C) ; buffer = bufs["tap." + name]
-    std::vector<void*> allocs;
-    std::vector<int*> g3, gup3, gup1;           // gather tables per level
-    bool geo_ok = true;                         // geo_source() reproduced every table on the host (mtv_create)
-    double* stats = nullptr;                     // GN site arenas: [2 step parities][STAT_COPIES][sites][max_batch][3][32][2]
-    size_t stats_bytes = 0;                     // bytes of ONE arena
-    size_t stats_copy_doubles = 0;              // doubles per privatised copy of an arena
-    int site_cursor = 0;
-    int site_parity = 0;                        // arena the plan being built uses
-    float* freqs = nullptr;
-    // external-layout staging (channel-major) and sampler state
-    float *xin = nullptr, *condin = nullptr, *icin = nullptr, *eps = nullptr;
-    int64_t* tbuf = nullptr;
-    // sampler state (mtv_ddim_sample): step table, per-call FiLM table, the head conv's hand-over records
-    DdimStep* d_steps = nullptr;
-    float *film_tab = nullptr, *sin_steps = nullptr, *e0_steps = nullptr, *e1_steps = nullptr;
-    int d_steps_cap = 0;
-    int* d_counter = nullptr;                   // [0] step index, [1] arrival counter of the head's workgroups
-    DdimFuse* d_fuse = nullptr;                 // [2]: one per step parity
-    char* h_pin[2] = {nullptr, nullptr};        // pinned upload staging (step table + hand-over records), double buffered
-    hipEvent_t pin_ev[2] = {nullptr, nullptr};
-    size_t pin_bytes = 0;
-    unsigned pin_turn = 0;
-    std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;   // (batch, mode)
-    hipStream_t cap_stream = nullptr;
-    bool eager = false;
-    mtv_work work{};
-    bool accounting = false;
-    float* staging = nullptr;
-    size_t staging_floats = 0;
-    std::map<int, size_t> slab_floats;                    // per batch size
-    std::map<std::string, ConvTile> tune_cache;           // conv shape -> measured best tile
-    void* flush = nullptr;                                // cache-flush scratch for cold auto-tune timing
-    size_t flush_bytes = 0;
-    bool tune_cache_loaded = false;                       // MTV_TUNE_CACHE=<file>: persisted across processes
-
-    // ---------------------------------------------------------------- memory helpers
-    int dmalloc(void** p, size_t bytes) {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-        if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-        allocs.push_back(*p);
-        return MTV_OK;
-    }
-    float* buf(const std::string& name, size_t floats) {
-        auto it = bufs.find(name);
-        if (it != bufs.end()) return it->second;
-        void* p = nullptr;
-        if (dmalloc(&p, floats * sizeof(float)) != MTV_OK) return nullptr;
-        (void)hipMemset(p, 0, floats * sizeof(float));
-        bufs[name] = (float*)p;
-        return (float*)p;
-    }
-    float* act(const std::string& name, int lvl, int C) {   // [max_batch][L_lvl][C]
-        float* p = buf("act." + name, (size_t)cfg.max_batch * lv[lvl].L * C);
-        taps[name] = {lvl, C};            // every activation is retrievable by name (mtv_debug_tap)
-        bufs["tap." + name] = p;
-        return p;
-    }
-    WSlot* slot(const std::string& key, std::vector<int64_t> shape, Role role, float* dst, int ld) {
-        auto it = slot_index.find(key);
-        if (it != slot_index.end()) return &slots[it->second];
-        slots.push_back(WSlot{key, std::move(shape), role, dst, ld, false});
-        slot_index[key] = (int)slots.size() - 1;
-        return &slots.back();
-    }
-    // plain-copied vector / matrix parameter
-    float* wcopy(const std::string& key, std::vector<int64_t> shape) {
-        size_t n = 1;
-        for (auto d : shape) n *= (size_t)d;
-        float* p = buf("w." + key, n);
-        slot(key, shape, ROLE_COPY, p, 0);
-        return p;
-    }
-    double* new_site() {
-        double* p = stats + (size_t)site_parity * stats_copy_doubles * STAT_COPIES + (size_t)site_cursor * cfg.max_batch * 192;
-        ++site_cursor;
-        return p;
-    }
-    ~mtv_ctx() {     // every exit path of mtv_create / mtv_destroy ends here: nothing device-side outlives the context
-        int cur = 0;
-        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != device;
-        if (sw) (void)hipSetDevice(device);
-        (void)hipDeviceSynchronize();
-        for (auto& kv : plans)
-            if (kv.second->g_forward) (void)hipGraphExecDestroy(kv.second->g_forward);
-        plans.clear();
-        if (cap_stream) (void)hipStreamDestroy(cap_stream);
-        for (void* p : allocs) (void)hipFree(p);
-        if (staging) (void)hipFree(staging);
-        free_step_tables();
-        for (int i = 0; i < 2; ++i) {
-            if (h_pin[i]) (void)hipHostFree(h_pin[i]);
-            if (pin_ev[i]) (void)hipEventDestroy(pin_ev[i]);
-        }
-        if (sw) (void)hipSetDevice(cur);
-    }
-    void free_step_tables() {
-        for (void* p : {(void*)d_steps, (void*)film_tab, (void*)sin_steps, (void*)e0_steps, (void*)e1_steps})
-            if (p) (void)hipFree(p);
-        d_steps = nullptr;
-        film_tab = sin_steps = e0_steps = e1_steps = nullptr;
-        d_steps_cap = 0;
-    }
-};
 
 // =====================================================================================
 // structure (mirrors unet.py:710-975 for dims=2, resblock_updown=True, legacy attention)
@@ -482,9 +269,18 @@ struct Builder {
             if (a0.gather_skip) a0.geo_skip = a0.gather_skip == c->gup1[lo] ? 2 : 0;
         }
         const int nchunks = a0.ntaps * (a0.Cmain / 16) + a0.Cskip / 16;
+        if (a0.gn.sums) {      // reciprocals the kernel multiplies by (GroupNorm: 1/gs, 1/(tokens x gs) per plane / overall)
+            const SegInfo& sg = a0.seg_src;
+            const double gs = (double)a0.gn.gs;
+            a0.gn.inv_gs = 1.0f / (float)a0.gn.gs;
+            a0.gn.inv_n[0] = 1.0 / ((double)sg.b1 * gs);
+            a0.gn.inv_n[1] = 1.0 / ((double)(sg.b2 - sg.b1) * gs);
+            a0.gn.inv_n[2] = 1.0 / ((double)(sg.L - sg.b2) * gs);
+            a0.gn.inv_n[3] = 1.0 / ((double)sg.L * gs);
+        }
         account_conv(a0);
         static const bool stamps_env = getenv("MTV_STAMPS") != nullptr;      // diagnostic build only (mtv_debug_stamps)
-        if (stamps_env) a0.dbg = reinterpret_cast<unsigned long long*>(c->buf("dbg." + name + "." + std::to_string(mode) + "." + std::to_string(B), 64));
+        if (stamps_env) a0.dbg = reinterpret_cast<unsigned long long*>(c->buf("dbg." + name + "." + std::to_string(mode) + "." + std::to_string(B), 128));
         auto op = std::make_shared<ConvOp>();
         op->a = a0;
         op->t = conv_pick_tile(B, a0.Lout, a0.N, nchunks, a0.Cmain, a0.gn.sums != nullptr);
@@ -513,7 +309,7 @@ struct Builder {
             int coff = 0;
             for (auto& p : parts) {
                 ConvArgs& pa = producer[p.p]->a;
-                pa.stat[pa.nstat++] = StatOut{site, ct / 32, coff};
+                pa.stat[pa.nstat++] = StatOut{site, ct / 32, coff, 1.0f / (float)(ct / 32)};
                 coff += p.C;
             }
             return;
@@ -669,7 +465,7 @@ struct Builder {
         const int H = f.num_heads;
         if (C % H || (C / H) % 4 || C % 32) { err = "attention channels/heads unsupported at " + P; return Tens{}; }
         const int d = C / H;
-        if (!(d == 4 || d == 8 || d == 16 || d == 32 || d == 64 || d == 128)) { err = "head dim unsupported at " + P; return Tens{}; }
+        if (!(d == 4 || d == 8 || d == 16 || d == 32 || d == 48 || d == 64 || d == 128)) { err = "head dim unsupported at " + P; return Tens{}; }
         float* gw = gnvec(P + "norm.weight", C);
         float* gb = gnvec(P + "norm.bias", C);
         const int ldq = pad64(3 * C);
@@ -841,31 +637,7 @@ struct Builder {
             add_conv(a, "head", 0);
         }
         if (c->site_cursor > c->n_sites) return fail(MTV_ERR_INVALID, "GN site arena overflow");
-        {   // one slab shared by every cross-workgroup split-K conv of this plan (they run back to back);
-            // sized so the auto-tuner may try up to 16 K slices wherever that stays under 64 MB
-            size_t need = 0;
-            for (auto& op : plan->convs) {
-                const size_t one = (size_t)B * op->a.Lout * op->a.N;
-                size_t ks = 16;
-                while (ks > 1 && ks * one * 4 > ((size_t)64 << 20)) ks /= 2;
-                if ((size_t)op->t.KS > ks) ks = op->t.KS;
-                need = ks * one > need ? ks * one : need;
-            }
-            float* slab = c->buf("slab.B" + std::to_string(B), need);
-            if (!slab) return fail(MTV_ERR_HIP, "slab allocation failed");
-            c->slab_floats[B] = need;
-            for (auto& op : plan->convs) op->a.slab = slab;
-            // arrival counters of the in-launch split-K completion: one per 16x16 output tile (the finest tiling),
-            // zeroed once here; every launch leaves them at zero again
-            size_t nt = 0;
-            for (auto& op : plan->convs) nt += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
-            int* tk = (int*)c->buf("tickets.B" + std::to_string(B), nt);
-            if (!tk) return fail(MTV_ERR_HIP, "ticket allocation failed");
-            for (auto& op : plan->convs) {
-                op->a.tickets = tk;
-                tk += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
-            }
-        }
+        { const int rcs = finish_split_k(c, plan); if (rcs != MTV_OK) return rcs; }
         if (c->accounting) c->work.n_launches = (int)plan->ops.size();
         return MTV_OK;
     }
@@ -875,6 +647,35 @@ struct Builder {
 
 // Empirical tile selection: every distinct conv shape of the plan is timed once over the valid
 // (MT, NT, NW, KS) candidates with its real arguments (MTV_AUTOTUNE=0 keeps the analytic pick).
+// One slab shared by every cross-workgroup split-K conv of a plan (they run back to back), sized so the auto-tuner may
+// try up to 16 K slices wherever that stays under 64 MB; plus the arrival counters of the in-launch split-K completion:
+// one per 16x16 output tile (the finest tiling), zeroed once here -- every launch leaves them at zero again.
+int finish_split_k(mtv_ctx* c, Plan* plan) {
+    const int B = plan->B;
+    const std::string tag = std::to_string(B) + (plan->mode >= MODE_AE_DECODE ? ".ae" : "");
+    size_t need = 0;
+    for (auto& op : plan->convs) {
+        const size_t one = (size_t)B * op->a.Lout * op->a.N;
+        size_t ks = 16;
+        while (ks > 1 && ks * one * 4 > ((size_t)64 << 20)) ks /= 2;
+        if ((size_t)op->t.KS > ks) ks = op->t.KS;
+        need = ks * one > need ? ks * one : need;
+    }
+    float* slab = c->buf("slab.B" + tag, need);
+    if (!slab) return fail(MTV_ERR_HIP, "slab allocation failed");
+    if (c->slab_floats[B] < need) c->slab_floats[B] = need;
+    for (auto& op : plan->convs) op->a.slab = slab;
+    size_t nt = 0;
+    for (auto& op : plan->convs) nt += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
+    int* tk = (int*)c->buf("tickets.B" + tag + ".m" + std::to_string(plan->mode >= MODE_AE_DECODE ? plan->mode : 0), nt);
+    if (!tk) return fail(MTV_ERR_HIP, "ticket allocation failed");
+    for (auto& op : plan->convs) {
+        op->a.tickets = tk;
+        tk += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
+    }
+    return MTV_OK;
+}
+
 // Tile table.  moditalker_amd/csrc/tune_gfx950.txt (committed, next to the library) holds the measured best tile
 // of every conv shape of the BASELINE configurations, so a fresh process reproduces the same launch plan without
 // timing anything; shapes it does not list are tuned on first use.  MTV_TUNE_CACHE=<file> replaces it (and is
@@ -917,7 +718,7 @@ static void tune_cache_append(const char* key, const ConvTile& t) {
     }
 }
 
-static int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
+int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     if (p->tuned) return MTV_OK;
     p->tuned = true;
     tune_cache_load(c);
@@ -1032,7 +833,7 @@ static int get_plan(mtv_ctx* c, int B, int mode, Plan** out) {
     return MTV_OK;
 }
 
-static int run_ops(mtv_ctx* c, Plan* p, hipStream_t s) {
+int run_ops(mtv_ctx* c, Plan* p, hipStream_t s) {
     for (auto& op : p->ops) {
         hipError_t e = op.run(s);
         if (e != hipSuccess) return fail(MTV_ERR_HIP, "launch " + op.name + ": " + hipGetErrorString(e));
@@ -1047,6 +848,17 @@ extern "C" {
 
 const char* mtv_last_error(void) { return g_err.c_str(); }
 int mtv_version(void) { return 1; }
+
+}  // extern "C"
+
+int ctx_init_common(mtv_ctx* c) {
+    HIPCHK(hipGetDevice(&c->device));
+    if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIPCHK(conv_init_attrs());     // dynamic LDS above 64 KB must be opted into once per kernel (never under capture)
+    return MTV_OK;
+}
+
+extern "C" {
 
 int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
     if (!cfg || !out) return fail(MTV_ERR_INVALID, "null argument");
@@ -1124,8 +936,7 @@ int mtv_create(const mtv_config* cfg, mtv_ctx** out) {
         if ((rc = c->dmalloc((void**)&c->freqs, half * 4)) != MTV_OK) return rc;
         HIPCHK(hipMemcpy(c->freqs, fr.data(), half * 4, hipMemcpyHostToDevice));
     }
-    HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-    HIPCHK(conv_init_attrs());
+    if ((rc = ctx_init_common(c.get())) != MTV_OK) return rc;
     // build the batch-1 plan now: registers every weight slot and fills the work accounting
     c->accounting = true;
     Plan* p1 = nullptr;
@@ -1190,6 +1001,18 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
     HIPCHK(hipSetDevice(c->device));
     if (s.role == ROLE_COPY) {
         HIPCHK(hipMemcpy(s.dst, data, n * sizeof(float), hipMemcpyDefault));
+    } else if (s.role == ROLE_REPEAT || s.role == ROLE_QKV_HEADS) {
+        if (c->staging_floats < n) {
+            if (c->staging) (void)hipFree(c->staging);
+            c->staging = nullptr;
+            c->staging_floats = 0;
+            HIPCHK(hipMalloc((void**)&c->staging, n * sizeof(float)));
+            c->staging_floats = n;
+        }
+        HIPCHK(hipMemcpy(c->staging, data, n * sizeof(float), hipMemcpyDefault));
+        if (s.role == ROLE_REPEAT) HIPCHK(launch_repeat(c->staging, s.dst, (int)n, s.aux, nullptr));
+        else HIPCHK(launch_repack_qkv(c->staging, s.dst, (int)s.shape[0] / (3 * s.aux), s.aux, (int)s.shape[1], s.ld, nullptr));
+        HIPCHK(hipStreamSynchronize(nullptr));
     } else {
         if (c->staging_floats < n) {
             if (c->staging) (void)hipFree(c->staging);
@@ -1208,7 +1031,9 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
     return MTV_OK;
 }
 
-static int check_ready(mtv_ctx* c, int batch) {
+}  // extern "C"
+
+int check_ready(mtv_ctx* c, int batch) {
     if (!c) return fail(MTV_ERR_INVALID, "null context");
     if (batch < 1 || batch > c->cfg.max_batch) return fail(MTV_ERR_STATE, "batch outside [1, max_batch]");
     const int miss = mtv_weights_missing(c);
@@ -1221,6 +1046,8 @@ static int check_ready(mtv_ctx* c, int batch) {
     return MTV_OK;
 }
 
+extern "C" {
+
 static int stage_inputs(mtv_ctx* c, const float* x, const float* cond, const float* image_cond, int ic_len, int B, hipStream_t s) {
     const int L = c->lv[0].L, RR = c->lv[0].b1;
     if (ic_len < RR) return fail(MTV_ERR_INVALID, "image_cond has fewer than R*R tokens");
@@ -1230,7 +1057,9 @@ static int stage_inputs(mtv_ctx* c, const float* x, const float* cond, const flo
     return MTV_OK;
 }
 
-static int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out) {
+}  // extern "C"
+
+int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = run_ops(c, p, c->cap_stream);
@@ -1245,6 +1074,8 @@ static int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out) {
     if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
     return MTV_OK;
 }
+
+extern "C" {
 
 int mtv_forward(mtv_ctx* c, const float* x, const float* cond, const float* image_cond, int image_cond_len,
                 const int64_t* timesteps, float* eps_out, int batch, void* stream) {
@@ -1442,19 +1273,19 @@ int mtv_debug_stamps(mtv_ctx* c, int batch, const char* path, void* stream) {
     for (int it = 0; it < 3; ++it) {
         if ((rc = sampler_setup(c, batch, nullptr, &one, 1, s)) != MTV_OK) return rc;
         for (auto& op : p->convs)
-            if (op->a.dbg) HIPCHK(hipMemsetAsync(op->a.dbg, 0, 256, s));
+            if (op->a.dbg) HIPCHK(hipMemsetAsync(op->a.dbg, 0, 512, s));
         if ((rc = run_ops(c, p, s)) != MTV_OK) return rc;
         HIPCHK(hipStreamSynchronize(s));
     }
     FILE* f = fopen(path, "w");
     if (!f) return fail(MTV_ERR_INVALID, "cannot open stamp file");
-    fprintf(f, "# per conv: name, then 4 sampled blocks (first, second, middle, last) x stamps[0..7]: 7=entry 0=decoded 1=ring issued 2=prologue done 3=K loop done 4=reduced 5=epilogue stored 6=statistics done (0 = path not taken)\n");
+    fprintf(f, "# per conv: name, then 4 sampled blocks (first, second, middle, last) x stamps[0..15]: 7=entry 0=decoded 8=tables built 9=barrier passed 10=first chunk requested 1=ring issued 2=prologue done 3=K loop done 4=reduced 5=epilogue stored 6=statistics done (0 = path not taken)\n");
     for (auto& op : p->convs) {
         if (!op->a.dbg) continue;
-        unsigned long long h[32];
+        unsigned long long h[64];
         HIPCHK(hipMemcpy(h, op->a.dbg, sizeof h, hipMemcpyDeviceToHost));
         fprintf(f, "%s", p->ops[op->op_index].name.c_str());
-        for (int i = 0; i < 32; ++i) fprintf(f, " %llu", h[i]);
+        for (int i = 0; i < 64; ++i) fprintf(f, " %llu", h[i]);
         fprintf(f, "\n");
     }
     fclose(f);

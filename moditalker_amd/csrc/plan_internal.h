@@ -1,0 +1,231 @@
+// Host-side structures shared by plan.hip (UNet plans, C ABI) and ae.hip (autoencoder plans): the context (device
+// buffers, weight slots, tile table, launch plans) and the plan / op records.  Internal; gfx950 only.
+#pragma once
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mtv_hip.h"
+#include "mtv_internal.h"
+
+using namespace mtv;
+
+// error text of the calling thread (mtv_last_error); defined in plan.hip
+int fail(int code, const std::string& msg);
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(MTV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));              \
+    } while (0)
+
+
+struct Level {
+    int r, t, L, b1, b2;
+    SegInfo seg() const { return SegInfo{b1, b2, L}; }
+};
+
+// how mtv_load_weight stores a tensor: COPY as is; CONV: OIHW / [O][I][1] / [O][I] -> [tap][I][ld] (output channels
+// contiguous); QKV_HEADS: a Linear [3*H*d][I] whose rows are (q|k|v, head, d) -> [I][ld] with columns (head, q|k|v, d),
+// the layout k_attention reads (aux = d); REPEAT: every element repeated aux times (a per-channel bias expanded over
+// the aux = patch*patch pixels of a ConvTranspose output)
+enum Role { ROLE_COPY = 0, ROLE_CONV = 1, ROLE_QKV_HEADS = 2, ROLE_REPEAT = 3 };
+
+struct WSlot {
+    std::string key;
+    std::vector<int64_t> shape;
+    Role role;
+    float* dst;
+    int ld;         // ROLE_CONV: leading dimension (padded output channels)
+    bool loaded;
+    int aux = 0;    // ROLE_QKV_HEADS: head dim; ROLE_REPEAT: repeat count
+};
+
+struct Tens {
+    float* p = nullptr;
+    int C = 0;
+    int lvl = 0;
+};
+
+struct ResDesc {
+    int cin, cout, updown;   // updown: 0 none, 1 down, 2 up
+    int film_off;
+};
+struct Layer {
+    int type;                // 0 stem conv, 1 resblock, 2 attention (2-D, per plane)
+    ResDesc res;
+    int c;
+    std::string pre;
+};
+struct Stage {
+    std::vector<Layer> layers;
+    int attn1_c = 0;         // channels of the cross-plane AttentionBlock1D after the stage (0: Identity)
+    std::string attn1_pre;
+    std::string tap;
+};
+
+struct Op {
+    std::function<hipError_t(hipStream_t)> run;
+    std::string name;
+    double flops = 0.0;    // algorithmic FLOPs of this launch (at the plan's batch size)
+    double bytes = 0.0;    // algorithmic HBM bytes: weights once + activations in/out once
+};
+
+struct ConvOp {                 // one convolution of the plan; args/tile are patched after creation
+    ConvArgs a;                 // (statistics targets, slab, auto-tuned tile), so launches read them late
+    ConvTile t;
+    std::string base_name;
+    int op_index = -1;
+};
+
+// A plan is built per (batch size, mode).  FORWARD: one UNetModel.forward for arbitrary per-clip timesteps
+// (time-embedding chain + input packing + UNet -> eps).  STEP0 / STEP1: one denoising step of the sampler, UNet
+// launches ONLY -- FiLM rows come from a per-call table, the sample is packed by the previous step's head conv,
+// the DDIM update runs in the head conv's epilogue; the two differ in the GroupNorm statistics arena they use
+// (a step's head zeroes the other parity's arena, so no memset launch either).
+enum Mode { MODE_FORWARD = 0, MODE_STEP0 = 1, MODE_STEP1 = 2, MODE_AE_DECODE = 3, MODE_AE_EXTRACT = 4 };
+
+struct Plan {
+    int B = 0;
+    int mode = MODE_FORWARD;
+    std::vector<std::shared_ptr<ConvOp>> convs;
+    bool tuned = false;
+    std::vector<Op> ops;           // UNet forward
+    hipGraphExec_t g_forward = nullptr;
+};
+
+
+struct mtv_ctx {
+    mtv_config cfg{};
+    int device = 0;
+    std::vector<Level> lv;
+    std::vector<Stage> inputs, outputs;
+    Stage middle;
+    int film_total = 0;
+    int n_sites = 0;
+    int emb_dim = 0;
+
+    std::vector<WSlot> slots;
+    std::map<std::string, int> slot_index;
+    std::map<std::string, float*> bufs;         // named activation / weight buffers
+    std::map<std::string, std::pair<int, int>> taps;   // tap name -> (level, C) ; buffer = bufs["tap." + name]
+    std::vector<void*> allocs;
+    std::vector<int*> g3, gup3, gup1;           // gather tables per level
+    bool geo_ok = true;                         // geo_source() reproduced every table on the host (mtv_create)
+    double* stats = nullptr;                     // GN site arenas: [2 step parities][STAT_COPIES][sites][max_batch][3][32][2]
+    size_t stats_bytes = 0;                     // bytes of ONE arena
+    size_t stats_copy_doubles = 0;              // doubles per privatised copy of an arena
+    int site_cursor = 0;
+    int site_parity = 0;                        // arena the plan being built uses
+    float* freqs = nullptr;
+    // external-layout staging (channel-major) and sampler state
+    float *xin = nullptr, *condin = nullptr, *icin = nullptr, *eps = nullptr;
+    int64_t* tbuf = nullptr;
+    // sampler state (mtv_ddim_sample): step table, per-call FiLM table, the head conv's hand-over records
+    DdimStep* d_steps = nullptr;
+    float *film_tab = nullptr, *sin_steps = nullptr, *e0_steps = nullptr, *e1_steps = nullptr;
+    int d_steps_cap = 0;
+    int* d_counter = nullptr;                   // [0] step index, [1] arrival counter of the head's workgroups
+    DdimFuse* d_fuse = nullptr;                 // [2]: one per step parity
+    char* h_pin[2] = {nullptr, nullptr};        // pinned upload staging (step table + hand-over records), double buffered
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    unsigned pin_turn = 0;
+    std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;   // (batch, mode)
+    hipStream_t cap_stream = nullptr;
+    bool eager = false;
+    mtv_work work{};
+    bool accounting = false;
+    float* staging = nullptr;
+    size_t staging_floats = 0;
+    std::map<int, size_t> slab_floats;                    // per batch size
+    std::map<std::string, ConvTile> tune_cache;           // conv shape -> measured best tile
+    void* flush = nullptr;                                // cache-flush scratch for cold auto-tune timing
+    size_t flush_bytes = 0;
+    bool tune_cache_loaded = false;                       // MTV_TUNE_CACHE=<file>: persisted across processes
+
+    // ---------------------------------------------------------------- memory helpers
+    int dmalloc(void** p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        allocs.push_back(*p);
+        return MTV_OK;
+    }
+    float* buf(const std::string& name, size_t floats) {
+        auto it = bufs.find(name);
+        if (it != bufs.end()) return it->second;
+        void* p = nullptr;
+        if (dmalloc(&p, floats * sizeof(float)) != MTV_OK) return nullptr;
+        (void)hipMemset(p, 0, floats * sizeof(float));
+        bufs[name] = (float*)p;
+        return (float*)p;
+    }
+    float* act(const std::string& name, int lvl, int C) {   // [max_batch][L_lvl][C]
+        float* p = buf("act." + name, (size_t)cfg.max_batch * lv[lvl].L * C);
+        taps[name] = {lvl, C};            // every activation is retrievable by name (mtv_debug_tap)
+        bufs["tap." + name] = p;
+        return p;
+    }
+    WSlot* slot(const std::string& key, std::vector<int64_t> shape, Role role, float* dst, int ld) {
+        auto it = slot_index.find(key);
+        if (it != slot_index.end()) return &slots[it->second];
+        slots.push_back(WSlot{key, std::move(shape), role, dst, ld, false});
+        slot_index[key] = (int)slots.size() - 1;
+        return &slots.back();
+    }
+    // plain-copied vector / matrix parameter
+    float* wcopy(const std::string& key, std::vector<int64_t> shape) {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        float* p = buf("w." + key, n);
+        slot(key, shape, ROLE_COPY, p, 0);
+        return p;
+    }
+    double* new_site() {
+        double* p = stats + (size_t)site_parity * stats_copy_doubles * STAT_COPIES + (size_t)site_cursor * cfg.max_batch * 192;
+        ++site_cursor;
+        return p;
+    }
+    ~mtv_ctx() {     // every exit path of mtv_create / mtv_destroy ends here: nothing device-side outlives the context
+        int cur = 0;
+        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != device;
+        if (sw) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        for (auto& kv : plans)
+            if (kv.second->g_forward) (void)hipGraphExecDestroy(kv.second->g_forward);
+        plans.clear();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        for (void* p : allocs) (void)hipFree(p);
+        if (staging) (void)hipFree(staging);
+        free_step_tables();
+        for (int i = 0; i < 2; ++i) {
+            if (h_pin[i]) (void)hipHostFree(h_pin[i]);
+            if (pin_ev[i]) (void)hipEventDestroy(pin_ev[i]);
+        }
+        if (sw) (void)hipSetDevice(cur);
+    }
+    void free_step_tables() {
+        for (void* p : {(void*)d_steps, (void*)film_tab, (void*)sin_steps, (void*)e0_steps, (void*)e1_steps})
+            if (p) (void)hipFree(p);
+        d_steps = nullptr;
+        film_tab = sin_steps = e0_steps = e1_steps = nullptr;
+        d_steps_cap = 0;
+    }
+};
+
+// ---- implemented in plan.hip, used by ae.hip ----
+int autotune(mtv_ctx* c, Plan* p, hipStream_t s);          // measured tile per conv shape (committed table first)
+int finish_split_k(mtv_ctx* c, Plan* p);                   // slab + arrival counters shared by the plan's split-K convs
+int run_ops(mtv_ctx* c, Plan* p, hipStream_t s);
+int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out);
+int check_ready(mtv_ctx* c, int batch);
+int ctx_init_common(mtv_ctx* c);                           // device, capture stream, kernel attributes

@@ -88,6 +88,23 @@ def fill_module_(module: torch.nn.Module, seed: int = 0, gain: float = 1.0, skip
         v.copy_(fill_tensor(k, tuple(v.shape), seed, gain).to(v.device, v.dtype))
 
 
+# ViTAutoencoder (the steps either side of the denoising loop): the recipe above applied to every parameter -- the
+# rotary-frequency buffers keep the values the reference computes -- with two per-key gains so that the sigmoid / tanh
+# output layers stay in their sensitive range (at gain 1 a random 8-layer transformer saturates them, and a saturated
+# output would hide errors from a parity test).
+AE_BUFFERS = ("inv_freqs", "scales", "coords")
+AE_KEY_GAINS = {"to_pixel.1.weight": 0.1, "pre_xy.weight": 0.1, "pre_yt.weight": 0.1, "pre_xt.weight": 0.1}
+
+
+@torch.no_grad()
+def fill_autoencoder_(module: torch.nn.Module, seed: int = 0) -> None:
+    fill_module_(module, seed=seed, skip_prefixes=AE_BUFFERS)
+    sd = module.state_dict()
+    for k, g in AE_KEY_GAINS.items():
+        if k in sd:
+            sd[k].mul_(g)
+
+
 def synthetic_inputs(batch: int, res: int, frames: int, seed: int = 0, tag: str = "clip"):
     """x [B,4,L], cond [B,8,L], image_cond [B,4,R*R], all U(-1,1) (AE latents are tanh outputs)."""
     L = res * res + 2 * frames * res

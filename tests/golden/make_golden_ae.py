@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Golden vectors for the autoencoder steps either side of the denoising loop, produced by
+running the REFERENCE's ViTAutoencoder itself (build container only; never on the GPU box).
+
+  MToV/models/autoencoder/autoencoder_vit.py  ViTAutoencoder.decode_from_sample / .extract   (imported unmodified)
+
+Weights by the arithmetic recipe of moditalker_amd/filler.py (the rotary-frequency buffers keep the values the reference
+computes), inputs by the same recipe.  Two geometries: the shipped one (resolution 256, 16 frames: 16384 tokens) and a
+small one (resolution 64, 16 frames: 1024 tokens) that the CPU suite can afford.  Also cross-checks oracle/ref_ae.py.
+Outputs: tests/golden/ae.npz (frames sub-sampled to keep the fixture small; full-frame checksums beside them).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference/MToV")
+
+from moditalker_amd import filler  # noqa: E402
+from oracle import ref_ae  # noqa: E402
+
+
+def ddconfig(res):
+    return dict(double_z=False, channels=384, resolution=res, timesteps=16, skip=1, in_channels=3, out_ch=3,
+                num_res_blocks=2, attn_resolutions=[], splits=1)
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 8)
+    from models.autoencoder.autoencoder_vit import ViTAutoencoder
+    out, report = {}, []
+    for tag, res, B, sub in (("small", 64, 2, 2), ("full", 256, 1, 5)):
+        seed = 21 if tag == "small" else 22
+        ae = ViTAutoencoder(4, ddconfig(res)).eval()
+        filler.fill_autoencoder_(ae, seed=seed)          # recipe + the two output-layer gains (filler.AE_KEY_GAINS)
+        sd = {k: v.clone() for k, v in ae.state_dict().items()}
+        r = res // 8
+        L = r * r + 2 * 16 * r
+        lat = filler.uniform_pm1(f"ae.{tag}.latent", (B, 4, L), seed)
+        vid = filler.uniform_pm1(f"ae.{tag}.video", (B, 3, 16, res, res), seed)
+        t0 = time.time()
+        with torch.no_grad():
+            frames = ae.decode_from_sample(lat)
+            t1 = time.time()
+            z = ae.extract(vid)
+        t2 = time.time()
+        print(f"reference {tag}: decode_from_sample {t1 - t0:.1f}s, extract {t2 - t1:.1f}s; frames std {float(frames.std()):.3f}, "
+              f"|frames|max {float(frames.abs().max()):.3f}, z std {float(z.std()):.3f}")
+        fo = ref_ae.decode_from_sample(sd, lat, res, 16)
+        zo = ref_ae.extract(sd, vid)
+        for nm, a, b in ((f"ae {tag} decode_from_sample", fo, frames), (f"ae {tag} extract", zo, z)):
+            d = float((a - b).abs().max())
+            report.append((nm, d))
+            print(f"  oracle vs reference  {nm:34s} max-abs {d:.3e}")
+            assert d <= 2e-5, (nm, d)
+        out[f"{tag}_seed"] = np.int64(seed)
+        out[f"{tag}_frames_sub{sub}"] = frames[:, :, ::sub, ::sub].contiguous().numpy()
+        out[f"{tag}_frames_mean_per_frame"] = frames.mean(dim=(1, 2, 3)).numpy()
+        out[f"{tag}_frames_abs_sum"] = np.float64(frames.double().abs().sum())
+        out[f"{tag}_extract"] = z.numpy()
+        if tag == "small":
+            out["keys"] = np.array(list(sd.keys()))
+            out["shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, "ae.npz"), **out)
+    print("ae.npz written")
+    with open(os.path.join(HERE, "PIN_REPORT.txt"), "a") as f:
+        f.write("# oracle/ref_ae.py vs imported reference ViTAutoencoder (make_golden_ae.py)\n")
+        for k, d in report:
+            f.write(f"{k:44s} {d:.3e}\n")
+
+
+if __name__ == "__main__":
+    main()

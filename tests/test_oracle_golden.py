@@ -80,3 +80,48 @@ def test_block_structure_matches_survey_counts():
     nattn1 = sum(1 for c in st["in_attn"] if c) + 1 + len(st["out_attn"])
     assert (nres, nattn2, nattn1) == (28, 16, 24)
     assert len(ref_unet.used_keys(BASE_CFG)) == 804 - 246  # 246 dead output_bg_* keys
+
+
+# ----------------------------------------------------------------------------------------------
+# autoencoder steps either side of the loop: oracle/ref_ae.py vs the reference's own outputs
+# ----------------------------------------------------------------------------------------------
+def _ae_state_dict(g, seed):
+    """Recipe-filled ViTAutoencoder state_dict from the key/shape manifest in the fixture; the rotary buffers are
+    recomputed exactly as the reference's constructors do (vit_modules.py:22-27, 51-55; autoencoder_vit.py:124-125)."""
+    import math
+    sd = {}
+    for k, shp in zip(g["keys"], g["shapes"]):
+        shape = tuple(int(x) for x in str(shp).split(",")) if str(shp) else ()
+        k = str(k)
+        if k.endswith("inv_freqs"):
+            sd[k] = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+        elif k.endswith("scales"):
+            sd[k] = torch.logspace(0.0, math.log(10 / 2) / math.log(2), 64 // 4, base=2)
+        elif k == "coords":
+            sd[k] = torch.linspace(-1, 1, steps=shape[0]).unsqueeze(-1)
+        else:
+            sd[k] = filler.fill_tensor(k, shape, seed) * filler.AE_KEY_GAINS.get(k, 1.0)
+    return sd
+
+
+@pytest.mark.parametrize("tag,res,B,sub", [("small", 64, 2, 2), ("full", 256, 1, 5)])
+def test_autoencoder_oracle_vs_reference_golden(tag, res, B, sub):
+    from oracle import ref_ae
+    g = np.load(os.path.join(GOLDEN, "ae.npz"))
+    seed = int(g[f"{tag}_seed"])
+    sd = _ae_state_dict(g, seed)
+    if tag == "full":       # same architecture, other resolution: only the two position-embedding tables change shape
+        for k in ("xt_pos_embedding", "yt_pos_embedding"):
+            sd[k] = filler.fill_tensor(k, (1, res // 8 + 1, 384), seed)
+    r = res // 8
+    L = r * r + 2 * 16 * r
+    lat = filler.uniform_pm1(f"ae.{tag}.latent", (B, 4, L), seed)
+    frames = ref_ae.decode_from_sample(sd, lat, res, 16)
+    assert frames.shape == (B * 16, 3, res, res)
+    assert float((frames[:, :, ::sub, ::sub] - torch.from_numpy(g[f"{tag}_frames_sub{sub}"])).abs().max()) <= TOL
+    assert float((frames.mean(dim=(1, 2, 3)) - torch.from_numpy(g[f"{tag}_frames_mean_per_frame"])).abs().max()) <= TOL
+    assert abs(float(frames.double().abs().sum()) - float(g[f"{tag}_frames_abs_sum"])) <= 1e-6 * float(g[f"{tag}_frames_abs_sum"])
+    vid = filler.uniform_pm1(f"ae.{tag}.video", (B, 3, 16, res, res), seed)
+    z = ref_ae.extract(sd, vid)
+    assert z.shape == (B, 4, L)
+    assert float((z - torch.from_numpy(g[f"{tag}_extract"])).abs().max()) <= TOL
