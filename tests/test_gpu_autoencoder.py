@@ -1,0 +1,153 @@
+"""GPU parity of the autoencoder steps either side of the denoising loop: the HIP path
+(C ABI mtv_ae_decode / mtv_ae_extract through moditalker_amd.ViTAutoencoder) against the golden vectors captured from the
+reference's own ViTAutoencoder (tests/golden/ae.npz) and against the CPU oracle, plus the end-to-end chain of BASELINE
+configs[4]: HIP sampler -> HIP decode, frame-MSE against oracle sampler -> oracle decode."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, SHALLOW_CFG
+from moditalker_amd import BASE_AE_DDCONFIG, DDPM, DiffusionWrapper, UNetModel, ViTAutoencoder, filler
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3      # BASELINE.json north_star: <= 1e-3 max-abs in fp32 (frames live in (-1, 1))
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _ae(res, seed, max_batch=1):
+    ae = ViTAutoencoder(4, dict(BASE_AE_DDCONFIG, resolution=res), max_batch=max_batch).eval()
+    filler.fill_autoencoder_(ae, seed=seed)
+    return ae.to(_dev())
+
+
+@pytest.mark.parametrize("tag,res,B,sub", [("small", 64, 2, 2), ("full", 256, 1, 5)])
+def test_decode_from_sample_vs_reference_golden(tag, res, B, sub):
+    g = np.load(os.path.join(GOLDEN, "ae.npz"))
+    seed = int(g[f"{tag}_seed"])
+    ae = _ae(res, seed, B)
+    r = res // 8
+    lat = filler.uniform_pm1(f"ae.{tag}.latent", (B, 4, r * r + 2 * 16 * r), seed)
+    frames = ae.decode_from_sample(lat.to(_dev())).cpu()
+    assert frames.shape == (B * 16, 3, res, res)
+    assert float(frames.abs().max()) < 1.0
+    d = float((frames[:, :, ::sub, ::sub] - torch.from_numpy(g[f"{tag}_frames_sub{sub}"])).abs().max())
+    assert d <= TOL, d
+    assert float((frames.mean(dim=(1, 2, 3)) - torch.from_numpy(g[f"{tag}_frames_mean_per_frame"])).abs().max()) <= 1e-4
+    assert abs(float(frames.double().abs().sum()) - float(g[f"{tag}_frames_abs_sum"])) <= 1e-4 * float(g[f"{tag}_frames_abs_sum"])
+
+
+@pytest.mark.parametrize("tag,res,B", [("small", 64, 2), ("full", 256, 1)])
+def test_extract_vs_reference_golden(tag, res, B):
+    g = np.load(os.path.join(GOLDEN, "ae.npz"))
+    seed = int(g[f"{tag}_seed"])
+    ae = _ae(res, seed, B)
+    vid = filler.uniform_pm1(f"ae.{tag}.video", (B, 3, 16, res, res), seed)
+    z = ae.extract(vid.to(_dev())).cpu()
+    r = res // 8
+    assert z.shape == (B, 4, r * r + 2 * 16 * r) and float(z.abs().max()) <= 1.0
+    d = float((z - torch.from_numpy(g[f"{tag}_extract"])).abs().max())
+    assert d <= TOL, d
+
+
+def test_decode_is_deterministic_and_batch_independent():
+    ae = _ae(64, 5, 3)
+    dev = _dev()
+    lat = filler.uniform_pm1("ae.det", (3, 4, 8 * 8 + 2 * 16 * 8), 5).to(dev)
+    a = ae.decode_from_sample(lat)
+    b = ae.decode_from_sample(lat)
+    assert torch.equal(a, b)
+    one = ae.decode_from_sample(lat[1:2])
+    assert float((a[16:32] - one).abs().max()) <= 2e-5      # another batch size may pick other tiles: summation order only
+
+
+def test_end_to_end_sampler_then_decode_frame_mse():
+    """BASELINE configs[4] at test size: DDIM sampler -> decode_from_sample -> clamp -> uint8 frames, the sequence of
+    sample.py:369-386, HIP against the CPU oracle on identical weights / noise; frame MSE and max-abs checked."""
+    from oracle import ref_ae, ref_ddpm, ref_unet
+    dev = _dev()
+    R, T, S = 8, 16, 6                         # 64x64 frames: latent side 8, 16 frames
+    cfg = dict(SHALLOW_CFG, image_size=R)
+    net = DiffusionWrapper(UNetModel(**cfg, frames=T, max_batch=1)).eval()
+    filler.fill_module_(net, seed=33, skip_prefixes=("output_bg_",))
+    sd_u = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    ae = _ae(64, 34)
+    sd_a = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
+    L = R * R + 2 * T * R
+    x, cond, ic = filler.synthetic_inputs(1, R, T, seed=33, tag="e2e")
+    noise = filler.noise_list(S, (1, 4, L), seed=33, tag="e2e.noise")
+    dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+    z = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=[n.to(dev) for n in noise])
+    frames = ae.decode_from_sample(z).clamp(-1, 1)
+    zr = ref_ddpm.ddim_sample(lambda a, b, c, d: ref_unet.unet_forward(sd_u, cfg, a, b, c, d, R, T), cond, ic, noise, S)
+    fr = ref_ae.decode_from_sample(sd_a, zr, 64, T).clamp(-1, 1)
+    assert float((z.cpu() - zr).abs().max()) <= TOL
+    mse = float(((frames.cpu() - fr) ** 2).mean())
+    assert mse <= 1e-7, mse
+    assert float((frames.cpu() - fr).abs().max()) <= TOL
+    u8, u8r = ((1 + frames.cpu()) * 127.5).to(torch.uint8), ((1 + fr) * 127.5).to(torch.uint8)     # sample.py:386-387
+    assert float((u8.int() - u8r.int()).abs().max()) <= 1
+
+
+def test_autoencoder_errors_are_loud():
+    ae = _ae(64, 5)
+    with pytest.raises(ValueError):
+        ae.decode_from_sample(torch.zeros(1, 4, 100, device=_dev()))
+    with pytest.raises(ValueError):
+        ae.extract(torch.zeros(1, 3, 8, 64, 64, device=_dev()))
+
+
+def test_two_chunk_chained_run_vs_oracle(tmp_path):
+    """--use_last_as_reference chaining (sample.py:344-362,388-398) through the library loop
+    (moditalker_amd.pipeline.MToVSampler) on the HIP sampler + HIP autoencoder, against the same sequence composed from the
+    CPU oracle's pieces: conditioning assembly (4 extracts, cat), sample, decode, 8-bit last frame -> next chunk's image_cond."""
+    from moditalker_amd import pipeline as P
+    from oracle import ref_ae, ref_ddpm, ref_unet
+    dev = _dev()
+    R, T, S, res = 8, 16, 4, 64
+    cfg = dict(SHALLOW_CFG, image_size=R)
+    net = DiffusionWrapper(UNetModel(**cfg, frames=T, max_batch=1)).eval()
+    filler.fill_module_(net, seed=41, skip_prefixes=("output_bg_",))
+    sd_u = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    ae = _ae(res, 42)
+    sd_a = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
+    L = R * R + 2 * T * R
+    dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+    sampler = P.MToVSampler(dm, ae, latent_res=R)
+    lm = np.stack([np.stack([np.array([20 + 3 * (i % 8) + f, 20 + 4 * (i // 8)]) for i in range(68)]) for f in range(T)])
+    chunks, noises = [], []
+    for it in range(2):
+        vid = (filler.uniform_pm1(f"chain.vid{it}", (1, T, 3, res, res), 41) + 1) * 127.5
+        ref = vid[:, :1].expand(-1, T, -1, -1, -1).contiguous()
+        x_l = torch.from_numpy(P.landmarks_to_images(lm * 4, WH=256)).float().permute(0, 3, 1, 2)[None, :, :, ::4, ::4].contiguous()
+        masked = vid.clone()
+        masked[:, :, :, res // 2:] = 0
+        chunks.append((ref, vid, x_l, masked))
+        noises.append(filler.noise_list(S, (1, 4, L), seed=41 + it, tag="chain.noise"))
+    out = sampler.run_identity([tuple(t.to(dev) for t in c) for c in chunks], use_last_as_reference=True, out_dir=str(tmp_path),
+                               noise_per_chunk=[[n.to(dev) for n in nz] for nz in noises])
+    # ---- the same sequence on the oracle
+    model = lambda a, b, c, d: ref_unet.unet_forward(sd_u, cfg, a, b, c, d, R, T)
+    image_cond, ref_out = None, []
+    for it, (ref, vid, x_l, masked) in enumerate(chunks):
+        xr, xv, xl, xm = (P.to_model_range(t) for t in (ref, vid, x_l, masked))
+        ic_ = ref_ae.extract(sd_a, xr)
+        c = torch.cat([ref_ae.extract(sd_a, xl), ref_ae.extract(sd_a, xm)], dim=1)
+        ic = image_cond if image_cond is not None else ic_[:, :, :R * R]
+        z = ref_ddpm.ddim_sample(model, c, ic, noises[it], S)
+        fake = (1 + ref_ae.decode_from_sample(sd_a, z, res, T).clamp(-1, 1).reshape(1, T, 3, res, res).permute(0, 1, 3, 4, 2)) * 127.5
+        last = np.rint(fake[:, -1].numpy()).clip(0, 255).astype(np.uint8)
+        image_cond = ref_ae.extract(sd_a, P.reference_from_uint8(last, T))[:, :, :R * R]
+        ref_out.append(fake.to(torch.uint8).numpy())
+    for a, b in zip(out, ref_out):
+        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        assert d.max() <= 2 and d.mean() <= 0.05, (int(d.max()), float(d.mean()))
+    assert len(os.listdir(tmp_path / "frames")) == 2 * T and (tmp_path / "references" / "16" / "0.png").exists()

@@ -166,3 +166,19 @@ def test_arithmetic_gather_matches_torch_unfold_semantics(R, T, levels):
                         else:
                             assert got >= 0 and (got & 0x0FFFFFFF) == want and (got >> 28) == p, (lvl, up, p, local, tap, got, want)
     assert lib.mtv_debug_gather_index(R, T, R * R + 2 * T * R, 1, 1, 0) == -2      # out of range -> error, not "padding"
+
+
+def test_autoencoder_state_dict_layout_matches_reference_manifest():
+    """415 keys, same names, order and shapes as the reference ViTAutoencoder.state_dict() (fixture written by
+    tests/golden/make_golden_ae.py from the imported reference at resolution 64)."""
+    from moditalker_amd import BASE_AE_DDCONFIG, ViTAutoencoder
+    g = np.load(os.path.join(GOLDEN, "ae.npz"))
+    with torch.device("meta"):
+        m = ViTAutoencoder(4, dict(BASE_AE_DDCONFIG, resolution=64))
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(x) for x in g["shapes"]]
+    with pytest.raises(NotImplementedError):
+        ViTAutoencoder(4, BASE_AE_DDCONFIG).forward(torch.zeros(1))
+    with pytest.raises(MtvError):                                   # off-GPU: loud, no CPU fallback
+        ViTAutoencoder(4, dict(BASE_AE_DDCONFIG, resolution=64)).decode_from_sample(torch.zeros(1, 4, 8 * 8 + 2 * 16 * 8))
