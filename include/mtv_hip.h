@@ -138,6 +138,10 @@ int mtv_profile_step(mtv_ctx* ctx, int batch, int iters, mtv_op_time* out, int c
  * with plain launches; the in-kernel phase timestamps of four sampled workgroups per conv are written to `path`. */
 int mtv_debug_stamps(mtv_ctx* ctx, int batch, const char* path, void* stream);
 
+/* Testing aid: plans built after this call run every eligible convolution on the LDS-tiled kernel k_conv_lds<wm, wn>
+ * (wave tile 16 wm x 16 wn, workgroup 2 x 2 waves) instead of the tuned choice; wm = 0 switches it off again. */
+int mtv_debug_force_lds(int wm, int wn);
+
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
 int mtv_set_eager(mtv_ctx* ctx, int eager);
 
@@ -184,6 +188,23 @@ int mtv_ae_decode(mtv_ctx* ctx, const float* latents, float* frames_out, int bat
 int mtv_ae_extract(mtv_ctx* ctx, const float* video, float* latents_out, int batch, void* stream);
 /* Per-launch hipEvent timing of decode (extract != 0: of extract), like mtv_profile_forward. */
 int mtv_ae_profile(mtv_ctx* ctx, int batch, int extract, int iters, mtv_op_time* out, int cap, int* n_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CrossAttention (unet.py:429-467) as a stand-alone operator: the one usable piece of the
+ * reference's dormant cross-attention conditioning (SpatialTransformer cannot be constructed there, unet.py:470-489,513).
+ * Weights through mtv_load_weight with the module's keys: "to_q.weight" [H*d, query_dim], "to_k.weight" / "to_v.weight"
+ * [H*d, context_dim], "to_out.0.weight" [query_dim, H*d], "to_out.0.bias" [query_dim].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mtv_xattn_config {
+    int32_t query_dim, context_dim, heads, dim_head;
+    int32_t max_batch, max_queries, max_keys;
+} mtv_xattn_config;
+int mtv_xattn_create(const mtv_xattn_config* cfg, mtv_ctx** out);
+int mtv_xattn_destroy(mtv_ctx* ctx);
+/* x [B, n_queries, query_dim]; context [B, n_keys, context_dim] or NULL (= x: self-attention); mask [B, n_keys] bytes or
+ * NULL (0 = key masked out, unet.py:452-456); out [B, n_queries, query_dim].  Device pointers. */
+int mtv_xattn_forward(mtv_ctx* ctx, const float* x, const float* context, const unsigned char* mask, float* out, int batch,
+                      int n_queries, int n_keys, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@ from ._lib import MtvError  # noqa: F401
 from .ddpm import DDPM, ddim_time_pairs, make_beta_schedule  # noqa: F401
 from .unet import DiffusionWrapper, UNetModel  # noqa: F401
 from .autoencoder import ViTAutoencoder  # noqa: F401
+from .cross_attention import CrossAttention  # noqa: F401
 
 BASE_AE_DDCONFIG = dict(  # MToV/configs/autoencoder/base.yaml:12-24 (embed_dim: 4)
     double_z=False, channels=384, resolution=256, timesteps=16, skip=1, in_channels=3, out_ch=3, num_res_blocks=2,

@@ -44,6 +44,10 @@ class MtvAeConfig(C.Structure):
                                          "dim_head", "max_batch")]
 
 
+class MtvXattnConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("query_dim", "context_dim", "heads", "dim_head", "max_batch", "max_queries", "max_keys")]
+
+
 class MtvDdimStep(C.Structure):
     _fields_ = [
         ("t", C.c_int32),
@@ -94,12 +98,16 @@ SYMBOLS = [
     ("mtv_profile_forward", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(MtvOpTime), C.c_int, C.POINTER(C.c_int), _P]),
     ("mtv_profile_step", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(MtvOpTime), C.c_int, C.POINTER(C.c_int), _P]),
     ("mtv_debug_stamps", C.c_int, [_P, C.c_int, C.c_char_p, _P]),
+    ("mtv_debug_force_lds", C.c_int, [C.c_int, C.c_int]),
     ("mtv_ae_create", C.c_int, [C.POINTER(MtvAeConfig), C.POINTER(_P)]),
     ("mtv_ae_destroy", C.c_int, [_P]),
     ("mtv_ae_set_rotary", C.c_int, [_P, _P, _P]),
     ("mtv_ae_decode", C.c_int, [_P, _P, _P, C.c_int, _P]),
     ("mtv_ae_extract", C.c_int, [_P, _P, _P, C.c_int, _P]),
     ("mtv_ae_profile", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(MtvOpTime), C.c_int, C.POINTER(C.c_int), _P]),
+    ("mtv_xattn_create", C.c_int, [C.POINTER(MtvXattnConfig), C.POINTER(_P)]),
+    ("mtv_xattn_destroy", C.c_int, [_P]),
+    ("mtv_xattn_forward", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("mtv_selftest_geometry", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_gather_index", C.c_int, [C.c_int] * 6),
 ]

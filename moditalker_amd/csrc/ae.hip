@@ -325,6 +325,7 @@ struct AeBuilder {
         auto op = std::make_shared<ConvOp>();
         op->a = a;
         op->t = conv_pick_tile(a.B, rows, N, K / 16, K, false);
+        force_lds_tile(a, &op->t);
         op->base_name = "gemm:" + name;
         op->op_index = (int)plan->ops.size();
         plan->convs.push_back(op);

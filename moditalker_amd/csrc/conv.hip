@@ -306,7 +306,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         if (a.geo_skip) return geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF;
         return a.gather_skip ? a.gather_skip[tok] : tok;
     };
-    for (int e = tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
+    // (the row table is built by the LAST threads of the workgroup, the chunk records above by the first ones: in an
+    // 8-wave workgroup no wave executes both, which halves the instructions on this serial stretch)
+    for (int e = NTH - 1 - tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
         const int t = e / ROWS, r = e - t * ROWS;
         const int tok = tok0 + r;
         int v = -1;
@@ -742,6 +744,328 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
+// k_conv_lds<WM, WN>: the same convolution for LARGE token counts (several clips batched on one GPU, the
+// 512x512 geometry, the autoencoder's 16384-token GEMMs), where k_conv's one-wave-one-tile operand delivery is
+// bound by the L2 -> CU path (measured: 6 KB per 32 MFMAs and wave at tile 32x64 = 47 B/clk/CU of the 64 B/clk a CU
+// can take).  A workgroup of 2 x 2 waves owns a (32 WM) x (32 WN) output tile and walks the whole K range; each
+// 16-channel chunk of A (rows gathered by tap, GroupNorm / FiLM / SiLU applied ONCE on the way) and of W is staged in
+// LDS by all 256 threads, double buffered (next chunk's global loads in flight under this chunk's MFMAs), and read
+// back as MFMA fragments by the four waves: 16 KB from L2 per 256 MFMAs instead of 48 KB.  Same arguments, same
+// epilogue semantics (bias, residual, statistics); no split-K (large M has enough tiles), token-major output only.
+// --------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
+    touch_kernargs<(int)sizeof(ConvArgs)>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float2 s_mr[3][32];
+    __shared__ f64x2 s_dp[96];
+    constexpr int BM = 32 * WM, BN = 32 * WN, NTH = 256;
+    constexpr int ASTR = 20;                    // floats per staged A row: 16 + 4 (16-byte fragment reads of 16 rows hit 16 distinct bank quads)
+    constexpr int BSTR = BN + 4;
+    constexpr int APT = BM / 64;                // A float4 per thread per chunk (row = tid/4 + 64 k, quad = tid & 3)
+    constexpr int BPT = BN / 64;                // W float4 per thread per chunk (k row = tid / (BN/4) + (1024/BN) k, column quad = tid % (BN/4))
+    constexpr int BROWS = 1024 / BN;            // W rows covered per pass of the 256 threads
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tiles_per_b = a.tiles_per_b, tiles_n = a.tiles_n;
+    const int blk = usgpr((int)blockIdx.x);
+    const int bx = usgpr(fdiv(blk, tiles_n, a.inv_tiles_n));           // column tiles fastest: neighbours share the A rows in L2
+    const int by = blk - bx * tiles_n;
+    const int b = usgpr(fdiv(bx, tiles_per_b, a.inv_tiles_per_b));
+    const int tok0 = (bx - b * tiles_per_b) * BM;
+    const int n0 = by * BN;
+    const int Cmain = a.Cmain;
+    const bool do_gn = a.gn.sums != nullptr;
+
+    // GroupNorm inputs first (needed last): see k_conv
+    constexpr int PER = 4;
+    f32x4 ga, be, s1, sh;
+    const float* film = (do_gn && a.gn.film) ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
+    auto fetch = [&](int c0) {
+        ga = *reinterpret_cast<const f32x4*>(a.gn.gamma + c0);
+        be = *reinterpret_cast<const f32x4*>(a.gn.beta + c0);
+        s1 = f32x4{1.f, 1.f, 1.f, 1.f};
+        sh = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (film) {
+            s1 += *reinterpret_cast<const f32x4*>(film + c0);
+            sh = *reinterpret_cast<const f32x4*>(film + Cmain + c0);
+        }
+    };
+    f64x2 v0 = {0.0, 0.0};
+    if (do_gn) {
+        if (tid * PER < Cmain) fetch(tid * PER);
+        if (tid < 96) {
+#pragma unroll
+            for (int k = 0; k < STAT_COPIES; ++k)
+                v0 += *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)tid * 2);
+        }
+    }
+
+    // ---- LDS: chunk records | row table [(ntaps+1)][BM] | coefficients | A stages | W stages | statistics slots
+    const int nchunks = a.cps_q;                                       // (KS * NW == 1 here: one slice = all chunks)
+    ChunkRec* recs = reinterpret_cast<ChunkRec*>(smem);
+    int* idx = reinterpret_cast<int*>(smem + a.rec_cap * 4);
+    const int idx_floats = ((a.ntaps + 1) * BM + 3) & ~3;
+    float2* coef = reinterpret_cast<float2*>(smem + a.rec_cap * 4 + idx_floats);
+    float* As = smem + a.rec_cap * 4 + idx_floats + (do_gn ? 6 * Cmain : 0);
+    float* Bs = As + 2 * BM * ASTR;
+    double* qs = reinterpret_cast<double*>(smem + a.qs_off);
+    {
+        const int nmainch = a.ntaps * a.cpt;
+        for (int e = tid; e < nchunks; e += NTH) {
+            const bool skip = e >= nmainch;
+            const int tap = skip ? a.ntaps : fdiv(e, a.cpt, a.inv_cpt);
+            const int w = skip ? e - nmainch : e - tap * a.cpt;
+            const int c0_16 = (skip ? a.C[2] : a.C[0]) >> 4;
+            const bool second = w >= c0_16;
+            const int c = (second ? w - c0_16 : w) << 4;
+            const float* sp = skip ? (second ? a.src[3] : a.src[2]) : (second ? a.src[1] : a.src[0]);
+            const int Cp = skip ? (second ? a.C[3] : a.C[2]) : (second ? a.C[1] : a.C[0]);
+            const int coff = second ? (skip ? a.C[2] : a.C[0]) : 0;
+            const unsigned long long ab = reinterpret_cast<unsigned long long>(sp) + (unsigned long long)c * 4ull;
+            ChunkRec r;
+            r.a_lo = (unsigned)(ab & 0xFFFFFFFFull);
+            r.a_hi = (unsigned)(ab >> 32);
+            r.wrow = (unsigned)((skip ? a.ntaps * Cmain : tap * Cmain) + coff + c);
+            r.meta = (unsigned)(coff + c) | ((unsigned)(Cp >> 4) << 16) | ((unsigned)tap << 24) | ((unsigned)(skip ? 1 : 0) << 28);
+            recs[e] = r;
+        }
+    }
+    auto skip_src = [&](int tok) -> int {
+        if (a.geo_skip) return geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF;
+        return a.gather_skip ? a.gather_skip[tok] : tok;
+    };
+    for (int e = NTH - 1 - tid; e < (a.ntaps + 1) * BM; e += NTH) {
+        const int t = e / BM, r = e - t * BM;
+        const int tok = tok0 + r;
+        int v = -1;
+        if (tok < a.Lout) {
+            if (t < a.ntaps) {
+                if (a.geo_main) {
+                    const int ky = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
+                    v = geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, ky, t - 3 * ky, a.geo_main == 2);
+                } else {
+                    const int st = a.gather ? a.gather[t * a.Lout + tok] : tok;
+                    v = st < 0 ? -1 : (st | (seg_of(a.seg_src, st) << 28));
+                }
+            } else {
+                v = skip_src(tok);
+            }
+        }
+        idx[e] = v;
+    }
+    for (int e = tid; e < 3 * (BN / 4) * 2; e += NTH) qs[e] = 0.0;
+    if (do_gn) {
+        const bool whole = a.gn.whole != 0;
+        if (whole) {
+            if (tid < 96) s_dp[tid] = v0;
+        }
+        __syncthreads();
+        if (tid < 96) {
+            const int sg = tid >> 5, g = tid & 31;
+            f64x2 v;
+            double inv_n;
+            if (whole) {
+                v = (s_dp[g] + s_dp[32 + g]) + s_dp[64 + g];
+                inv_n = a.gn.inv_n[3];
+            } else {
+                v = v0;
+                inv_n = a.gn.inv_n[sg];
+            }
+            const double mean = v[0] * inv_n;
+            double var = v[1] * inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_mr[sg][g] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
+        }
+        __syncthreads();
+        for (int c0 = tid * PER; c0 < Cmain; c0 += NTH * PER) {
+            if (c0 != tid * PER) fetch(c0);
+            int grp[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) grp[k] = fdiv(c0 + k, a.gn.gs, a.gn.inv_gs);
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg)
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const float2 mr = s_mr[sg][grp[k]];
+                    const float sc = mr.y * ga[k];
+                    const float bi = be[k] - sc * mr.x;
+                    coef[sg * Cmain + c0 + k] = make_float2(sc * s1[k], fmaf(bi, s1[k], sh[k]));
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- staging: global -> registers (raw) -> [transform] -> LDS
+    const bool act = a.gn.act != 0;
+    const unsigned bL[2] = {(unsigned)b * (unsigned)a.Lsrc, (unsigned)b * (unsigned)a.Lskip};
+    gchar* const Wg = (gchar*)(unsigned long long)a.W;
+    const unsigned ldw4 = (unsigned)a.ldw * 4u;
+    const int arow = tid >> 2, aq = tid & 3;               // this thread's A rows: arow + 64 k, channel quad aq
+    const int bcol = tid % (BN / 4), brow = tid / (BN / 4);
+    f32x4 ra[APT], rb[BPT];
+    int re[APT];
+    int rcc = 0, rskip = 0;
+    auto gload = [&](int ch) {
+        const ChunkRec* rp = recs + ch;
+        const unsigned a_lo = (unsigned)usgpr((int)rp->a_lo), a_hi = (unsigned)usgpr((int)rp->a_hi);
+        const unsigned wrow = (unsigned)usgpr((int)rp->wrow), meta = (unsigned)usgpr((int)rp->meta);
+        const int tap = (int)((meta >> 24) & 15u);
+        rskip = (int)(meta >> 28);
+        rcc = (int)(meta & 0xFFFFu);
+        const unsigned Cp4 = ((meta >> 16) & 0xFFu) << 6;
+        gchar* abase = (gchar*)(((unsigned long long)a_hi << 32) | a_lo);
+        const unsigned bl = rskip ? bL[1] : bL[0];
+#pragma unroll
+        for (int k = 0; k < APT; ++k) {
+            const int e = idx[tap * BM + arow + 64 * k];
+            re[k] = e;
+            const unsigned st = e < 0 ? 0u : (unsigned)(e & 0x0FFFFFFF);
+            ra[k] = *(const __attribute__((address_space(1))) f32x4*)(abase + ((bl + st) * Cp4 + 16u * aq));
+        }
+        gchar* wbase = Wg + (size_t)wrow * (size_t)ldw4;
+#pragma unroll
+        for (int k = 0; k < BPT; ++k)
+            rb[k] = n0 + 4 * bcol < a.ldw     // (a column tile may reach past the padded row of W: those columns are never stored)
+                        ? *(const __attribute__((address_space(1))) f32x4*)(wbase + ((unsigned)(brow + BROWS * k) * ldw4 + (unsigned)(n0 + 4 * bcol) * 4u))
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto lstore = [&](int buf) {
+        float* Ab = As + buf * BM * ASTR;
+        float* Bb = Bs + buf * 16 * BSTR;
+#pragma unroll
+        for (int k = 0; k < APT; ++k) {
+            f32x4 v = ra[k];
+            const int e = re[k];
+            if (do_gn && !rskip) {
+                const int sg = e < 0 ? 0 : ((e >> 28) & 3);
+                const f32x4* cf = reinterpret_cast<const f32x4*>(coef + sg * Cmain + rcc + 4 * aq);
+                const f32x4 k0 = cf[0], k1 = cf[1];
+                float y0 = fmaf(v[0], k0[0], k0[1]), y1 = fmaf(v[1], k0[2], k0[3]);
+                float y2 = fmaf(v[2], k1[0], k1[1]), y3 = fmaf(v[3], k1[2], k1[3]);
+                if (act) { y0 = silu_fast(y0); y1 = silu_fast(y1); y2 = silu_fast(y2); y3 = silu_fast(y3); }
+                v = f32x4{y0, y1, y2, y3};
+            }
+            if (e < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(Ab + (arow + 64 * k) * ASTR + 4 * aq) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) *reinterpret_cast<f32x4*>(Bb + (brow + BROWS * k) * BSTR + 4 * bcol) = rb[k];
+    };
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < WN; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        const float* Ab = As + buf * BM * ASTR + (wm * 16 * WM + i) * ASTR + 4 * q;
+        const float* Bb = Bs + buf * 16 * BSTR + (4 * q) * BSTR + wn * 16 * WN + WN * i;
+        f32x4 af[WM];
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(Ab + 16 * mt * ASTR);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float bv[WN];
+            if constexpr (WN == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(Bb + s * BSTR);
+                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+            } else {
+                const f32x2 t = *reinterpret_cast<const f32x2*>(Bb + s * BSTR);
+                bv[0] = t[0]; bv[1] = t[1];
+            }
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < WN; ++nb) acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][s], bv[nb], acc[mt][nb], 0, 0, 0);
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool more = ch + 1 < nchunks;
+        if (more) gload(ch + 1);                 // in flight under this chunk's MFMAs
+        compute(ch & 1);
+        if (more) lstore((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue straight from the accumulators: lane (i, q) of wave (wm, wn) holds, for row 4q + r of row block mt, the
+    // WN consecutive output channels n0 + 16 WN wn + WN i ..
+    const bool fast = a.nstat > 0;
+    const int colw = n0 + wn * 16 * WN + WN * i;
+    constexpr int QPR = BN / 4;
+    if (colw < a.N) {
+        float bias[WN];
+#pragma unroll
+        for (int nb = 0; nb < WN; ++nb) {
+            bias[nb] = a.bias[colw + nb];
+            if (a.bias2) bias[nb] += a.bias2[colw + nb];
+            if (a.bias_b) bias[nb] += a.bias_b[(size_t)b * a.bias_b_stride + colw + nb];
+        }
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 16 * WM + 16 * mt + 4 * q + r;
+                const int tok = tok0 + row;
+                if (tok >= a.Lout) continue;
+                float o[WN];
+#pragma unroll
+                for (int nb = 0; nb < WN; ++nb) o[nb] = acc[mt][nb][r] + bias[nb];
+                if (a.res) {
+                    const int rs = idx[a.ntaps * BM + row];
+                    const float* rp = a.res + ((size_t)b * a.Lskip + rs) * a.N + colw;
+#pragma unroll
+                    for (int nb = 0; nb < WN; ++nb) o[nb] += rp[nb];
+                }
+                float* op = a.out + ((size_t)b * a.Lout + tok) * a.N + colw;
+                if constexpr (WN == 4) *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
+                else *reinterpret_cast<f32x2*>(op) = f32x2{o[0], o[1]};
+                if (fast) {
+                    const int sgq = seg_of(a.seg_out, tok);
+                    double sq = 0.0, ssq = 0.0;
+#pragma unroll
+                    for (int nb = 0; nb < WN; ++nb) {
+                        sq += (double)o[nb];
+                        ssq += (double)o[nb] * o[nb];
+                    }
+                    const int cq = (colw - n0) >> 2;               // (WN == 2: two lanes share a quad slot)
+                    atomicAdd(&qs[(sgq * QPR + cq) * 2], sq);
+                    atomicAdd(&qs[(sgq * QPR + cq) * 2 + 1], ssq);
+                }
+            }
+    }
+    if (!fast) return;
+    __syncthreads();
+    for (int e = tid; e < a.nstat * 3 * QPR; e += NTH) {
+        const int t = e / (3 * QPR), r2 = e - t * 3 * QPR;
+        const int sgi = r2 / QPR, cq = r2 - sgi * QPR;
+        const int n = n0 + cq * 4;
+        if (n >= a.N) continue;
+        const int gs = a.stat[t].gs, coff = a.stat[t].coff;
+        const float inv_gs = a.stat[t].inv_gs;
+        const int g = fdiv(coff + n, gs, inv_gs);
+        if (cq > 0 && fdiv(coff + n - 4, gs, inv_gs) == g) continue;
+        const int qend = min(QPR, min((a.N - n0 + 3) >> 2, ((g + 1) * gs - coff - n0 + 3) >> 2));
+        double s = 0.0, ss = 0.0;
+        for (int c2 = cq; c2 < qend; ++c2) {
+            s += qs[(sgi * QPR + c2) * 2];
+            ss += qs[(sgi * QPR + c2) * 2 + 1];
+        }
+        if (ss != 0.0) {
+            double* dst = a.stat[t].sums + (size_t)(blockIdx.x & (STAT_COPIES - 1)) * a.stat_cstride + (((size_t)b * 3 + sgi) * 32 + g) * 2;
+            atomicAdd(dst, s);
+            atomicAdd(dst + 1, ss);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // tile / split selection: a small analytic cost model (times in microseconds)
 // --------------------------------------------------------------------------------------------
 // chunk records a workgroup needs room for: its NW slices of ceil-ish nchunks / (KS * NW) chunks each
@@ -766,6 +1090,51 @@ static size_t lds_bytes(int MT, int NT, int NW, int KS, int ntaps, int Cmain, in
     r = (r + 15) & ~(size_t)15;
     if (qs_off) *qs_off = (int)(r / 4);
     return r + (size_t)3 * (COLS / 4) * 2 * 8;                       // + per-(plane, quad) statistics
+}
+
+// k_conv_lds: tiles are encoded as ConvTile{WM, WN, NW = 32, KS = 1, XM = 0}
+static size_t lds_bytes_tiled(int WM, int WN, int ntaps, int Cmain, int Cskip, bool has_gn, int* qs_off = nullptr) {
+    const int BM = 32 * WM, BN = 32 * WN;
+    const int nchunks = ntaps * (Cmain / 16) + Cskip / 16;
+    size_t fl = (size_t)((nchunks + 3) & ~3) * 4 + (size_t)(((ntaps + 1) * BM + 3) & ~3) + (has_gn ? (size_t)6 * Cmain : 0) +
+                (size_t)2 * BM * 20 + (size_t)2 * 16 * (BN + 4);
+    fl = (fl + 3) & ~(size_t)3;
+    if (qs_off) *qs_off = (int)fl;
+    return fl * 4 + (size_t)3 * (BN / 4) * 2 * 8;
+}
+
+bool conv_lds_eligible(const ConvArgs& a) {
+    if (a.out_cm || a.ddim || (a.N & 3) || a.N < 64) return false;
+    for (int t = 0; t < a.nstat; ++t)
+        if (a.stat[t].gs & 3) return false;
+    return true;
+}
+
+template <int WM, int WN>
+static hipError_t launch_conv_lds_t(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    const int tiles = (a.Lout + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const long nblk = (long)a.B * tiles * tiles_n;
+    if (nblk >= (1L << 21) || !conv_lds_eligible(a)) return hipErrorInvalidValue;
+    const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
+    a.KS = 1;
+    a.xmap = 0;
+    a.tiles_per_b = tiles;
+    a.tiles_n = tiles_n;
+    a.Bt = a.B * tiles;
+    a.inv_tiles_per_b = 1.0f / (float)tiles;
+    a.inv_tiles_n = 1.0f / (float)tiles_n;
+    a.inv_Bt = 1.0f / (float)a.Bt;
+    a.cpt = a.Cmain / 16;
+    a.inv_cpt = 1.0f / (float)a.cpt;
+    a.geo_inv_r = a.geo_r > 0 ? 1.0f / (float)a.geo_r : 0.f;
+    a.cps_q = nchunks;
+    a.cps_r = 0;
+    a.rec_cap = (nchunks + 3) & ~3;
+    const size_t smem = lds_bytes_tiled(WM, WN, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr, &a.qs_off);
+    hipLaunchKernelGGL((k_conv_lds<WM, WN>), dim3((unsigned)nblk), dim3(256), smem, s, a);
+    return hipGetLastError();
 }
 
 ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn) {
@@ -826,6 +1195,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
 }
 
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
+    if (t.NW == 32) return lds_bytes_tiled(t.MT, t.NT, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
     return lds_bytes(t.MT, t.NT, t.NW, t.KS, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
 }
 
@@ -895,7 +1265,12 @@ hipError_t conv_init_attrs() {
     if ((e = conv_attr_nw<1, 4>()) != hipSuccess) return e;
     if ((e = conv_attr_nw<2, 2>()) != hipSuccess) return e;
     if ((e = conv_attr_nw<1, 2>()) != hipSuccess) return e;
-    return conv_attr_nw<1, 1>();
+    if ((e = conv_attr_nw<1, 1>()) != hipSuccess) return e;
+    const void* tiled[] = {reinterpret_cast<const void*>(&k_conv_lds<4, 4>), reinterpret_cast<const void*>(&k_conv_lds<2, 4>),
+                           reinterpret_cast<const void*>(&k_conv_lds<4, 2>), reinterpret_cast<const void*>(&k_conv_lds<2, 2>)};
+    for (const void* f : tiled)
+        if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
@@ -908,6 +1283,19 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
         a.xmap = 0;            // no padding blocks: every block of the grid takes part in the step hand-over
     }
     hipError_t e = hipErrorInvalidValue;
+    if (t.NW == 32 && !conv_lds_eligible(a)) {      // (statistics targets are attached after a plan's op is created)
+        t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);
+        t.KS = 1;
+        a.KS = 1;
+        a.xmap = t.XM;
+    }
+    if (t.NW == 32) {            // LDS-tiled kernel
+        if (t.MT == 4 && t.NT == 4) return launch_conv_lds_t<4, 4>(a, s);
+        if (t.MT == 2 && t.NT == 4) return launch_conv_lds_t<2, 4>(a, s);
+        if (t.MT == 4 && t.NT == 2) return launch_conv_lds_t<4, 2>(a, s);
+        if (t.MT == 2 && t.NT == 2) return launch_conv_lds_t<2, 2>(a, s);
+        return hipErrorInvalidValue;
+    }
     if (t.MT == 4 && t.NT == 4) e = launch_conv_nw<4, 4>(a, t.NW, s);
     else if (t.MT == 2 && t.NT == 4) e = launch_conv_nw<2, 4>(a, t.NW, s);
     else if (t.MT == 1 && t.NT == 4) e = launch_conv_nw<1, 4>(a, t.NW, s);

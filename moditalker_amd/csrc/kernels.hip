@@ -218,8 +218,16 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         start = a.seg_start[sg];
         len = a.seg_len[sg];
     }
-    const int RS = 3 * a.C;
-    const float* base = a.qkv + (size_t)b * a.L * RS + (size_t)h * 3 * D;
+    // self-attention: q | k | v of a head are adjacent in ONE buffer (row stride 3C).  Cross-attention (a.kv != nullptr,
+    // CrossAttention of unet.py:429-467): queries [B][L][C] (head-major), keys/values in a second buffer [B][Lkv][2C] with
+    // k | v of a head adjacent; one segment, every query sees all Lkv keys (minus the masked ones).
+    const bool cross = a.kv != nullptr;
+    const int RS = cross ? a.C : 3 * a.C;                              // query row stride
+    const int RSK = cross ? 2 * a.C : 3 * a.C;                         // key/value row stride
+    const float* base = a.qkv + (size_t)b * a.L * RS + (size_t)h * (cross ? D : 3 * D);
+    const float* kbase = cross ? a.kv + (size_t)b * a.Lkv * RSK + (size_t)h * 2 * D : base + D;   // -> k of key 0 (v follows at + D)
+    const int klen = cross ? a.Lkv : len, kstart = cross ? 0 : start;
+    const unsigned char* kmask = cross && a.kmask ? a.kmask + (size_t)b * a.Lkv : nullptr;
     const float scale = a.scale;
 
     if (D < 16) {   // rows D..15 of V^T are never written: keep them zero (they feed masked MFMA rows)
@@ -248,8 +256,8 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         for (int r = 0; r < NLD; ++r) {
             const int e = tid + NTH * r;
             const int key = e / QPR, qd = e - key * QPR;
-            const bool ok = e < KB * QPR && kb + key < len;
-            const float* p = base + (size_t)(start + (ok ? kb + key : 0)) * RS + D + qd * 4;
+            const bool ok = e < KB * QPR && kb + key < klen;
+            const float* p = kbase + (size_t)(kstart + (ok ? kb + key : 0)) * RSK + qd * 4;
             kreg[r] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
             vreg[r] = ok ? *reinterpret_cast<const f32x4*>(p + D) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -300,8 +308,10 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
             }
             if constexpr (!FULL) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kb + kt * 16 + 4 * g + r >= len) s4[r] = -INFINITY;
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + kt * 16 + 4 * g + r;
+                    if (key >= klen || (kmask && !kmask[key])) s4[r] = -INFINITY;     // past the end, or masked out (unet.py:452-456)
+                }
             }
             st[w] = s4;
         }
@@ -340,10 +350,10 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
             }
         }
     };
-    for (int kb = 0; kb < len; kb += KB) {
-        const bool more = kb + KB < len;
+    for (int kb = 0; kb < klen; kb += KB) {
+        const bool more = kb + KB < klen;
         if (more) gload(kb + KB);                       // in flight under this block's math
-        if (kb + KB <= len) block(kb, std::true_type{});
+        if (kb + KB <= klen && !kmask) block(kb, std::true_type{});
         else block(kb, std::false_type{});
         if (more) lstore(buf ^ 1);
         __syncthreads();

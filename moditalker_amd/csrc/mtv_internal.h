@@ -214,6 +214,11 @@ struct AttnArgs {
     // seg_uniform > 0 the token axis is cut into L / seg_uniform segments of that length and seg_start/len are unused
     int seg_uniform;
     int bps;                 // query blocks per uniform segment (set by launch_attention)
+    // cross-attention (CrossAttention, unet.py:429-467): `qkv` then holds the queries only ([B][L][C], head-major) and
+    // kv the keys/values [B][Lkv][2C] (k | v of a head adjacent); one segment of all L queries
+    const float* kv;
+    int Lkv;
+    const unsigned char* kmask;   // [B][Lkv] or nullptr: 0 = key masked out
 };
 
 struct LinearArgs {
@@ -245,6 +250,8 @@ __device__ __forceinline__ float ddim_update_elem(const DdimStep& st, float x, f
 
 // ---- launchers (kernels.hip) ----
 struct ConvTile { int MT, NT, NW, KS, XM; };   // XM: workgroup->tile mapping (0 rows fastest, 1 weight slice per XCD)
+                                               // NW == 32: the LDS-tiled kernel k_conv_lds<WM = MT, WN = NT> (KS = 1, XM = 0)
+bool conv_lds_eligible(const ConvArgs& a);
 ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn);
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s);
@@ -264,5 +271,6 @@ hipError_t launch_repack_conv(const float* src, float* dst, int N, int C, int nt
 // ---- autoencoder kernels (ae.hip) ----
 hipError_t launch_repack_qkv(const float* src, float* dst, int H, int d, int C, int ld, hipStream_t s);
 hipError_t launch_repeat(const float* src, float* dst, int n, int rep, hipStream_t s);
+hipError_t launch_repack_heads(const float* src, float* dst, int H, int d, int C, int ld, int nparts, int part, hipStream_t s);   // xattn.hip
 
 }  // namespace mtv

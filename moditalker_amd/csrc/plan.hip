@@ -284,6 +284,7 @@ struct Builder {
         auto op = std::make_shared<ConvOp>();
         op->a = a0;
         op->t = conv_pick_tile(B, a0.Lout, a0.N, nchunks, a0.Cmain, a0.gn.sums != nullptr);
+        force_lds_tile(a0, &op->t);
         op->base_name = std::string(a0.ntaps == 9 ? "conv3:" : "conv1:") + name;
         op->op_index = (int)plan->ops.size();
         producer[a0.out] = op;
@@ -647,6 +648,20 @@ struct Builder {
 
 // Empirical tile selection: every distinct conv shape of the plan is timed once over the valid
 // (MT, NT, NW, KS) candidates with its real arguments (MTV_AUTOTUNE=0 keeps the analytic pick).
+// testing aid: MTV_FORCE_LDS="WM,WN" (or mtv_debug_force_lds) runs every eligible conv of plans built afterwards on the
+// LDS-tiled kernel k_conv_lds<WM, WN>; a conv that turns out not to be eligible at launch falls back (launch_conv)
+static int g_force_wm = -1, g_force_wn = 0;
+void force_lds_tile(const ConvArgs& a, ConvTile* t) {
+    if (g_force_wm == -1) {
+        g_force_wm = 0;
+        if (const char* e = getenv("MTV_FORCE_LDS")) {
+            int x = 0, y = 0;
+            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 2 || x == 4) && (y == 2 || y == 4)) { g_force_wm = x; g_force_wn = y; }
+        }
+    }
+    if (g_force_wm > 0 && conv_lds_eligible(a)) *t = ConvTile{g_force_wm, g_force_wn, 32, 1, 0};
+}
+
 // One slab shared by every cross-workgroup split-K conv of a plan (they run back to back), sized so the auto-tuner may
 // try up to 16 K slices wherever that stays under 64 MB; plus the arrival counters of the in-launch split-K completion:
 // one per 16x16 output tile (the finest tiling), zeroed once here -- every launch leaves them at zero again.
@@ -723,7 +738,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     p->tuned = true;
     tune_cache_load(c);
     const char* env = getenv("MTV_AUTOTUNE");
-    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE")) return MTV_OK;
+    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0) return MTV_OK;
     static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
     struct Events {             // destroyed on every exit path (HIPCHK returns early)
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -752,10 +767,12 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
         if (it != c->tune_cache.end()) {             // an entry read from MTV_TUNE_CACHE is only trusted if it is launchable
             const ConvTile& t = it->second;
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
-            const bool shape_ok = (t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
-                                  (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
-                                  t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1);
-            if (!shape_ok || t.NW * t.KS > nchunks || (t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
+            const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
+            const bool shape_ok = tiled_ok ||
+                                  ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
+                                   (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
+                                   t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1));
+            if (!shape_ok || (!tiled_ok && t.NW * t.KS > nchunks) || (t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
                 conv_smem_bytes(a, t) > 120 * 1024) {
                 c->tune_cache.erase(it);
                 it = c->tune_cache.end();
@@ -804,6 +821,30 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                                 best = t;
                             }
                         }
+                    }
+                }
+            }
+            // the LDS-tiled kernel for large token counts (>= 2048 rows in all: fewer would leave most CUs idle)
+            if ((long)a.B * a.Lout >= 2048 && conv_lds_eligible(a)) {
+                static const int tl[][2] = {{4, 4}, {2, 4}, {4, 2}, {2, 2}};
+                for (auto& mn : tl) {
+                    const ConvTile t{mn[0], mn[1], 32, 1, 0};
+                    if ((long)a.B * ((a.Lout + 32 * t.MT - 1) / (32 * t.MT)) * ((a.N + 32 * t.NT - 1) / (32 * t.NT)) < 128) continue;
+                    if (conv_smem_bytes(a, t) > 120 * 1024) continue;
+                    float samp[16];
+                    HIPCHK(launch_conv(a, t, s));
+                    for (int w = 0; w < nsamp; ++w) {
+                        HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
+                        HIPCHK(hipEventRecord(e0, s));
+                        HIPCHK(launch_conv(a, t, s));
+                        HIPCHK(hipEventRecord(e1, s));
+                        HIPCHK(hipEventSynchronize(e1));
+                        HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
+                    }
+                    std::sort(samp, samp + nsamp);
+                    if (samp[nsamp / 2] < best_ms) {
+                        best_ms = samp[nsamp / 2];
+                        best = t;
                     }
                 }
             }
@@ -1001,7 +1042,7 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
     HIPCHK(hipSetDevice(c->device));
     if (s.role == ROLE_COPY) {
         HIPCHK(hipMemcpy(s.dst, data, n * sizeof(float), hipMemcpyDefault));
-    } else if (s.role == ROLE_REPEAT || s.role == ROLE_QKV_HEADS) {
+    } else if (s.role == ROLE_REPEAT || s.role == ROLE_QKV_HEADS || s.role == ROLE_KV_HEADS) {
         if (c->staging_floats < n) {
             if (c->staging) (void)hipFree(c->staging);
             c->staging = nullptr;
@@ -1011,6 +1052,8 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
         }
         HIPCHK(hipMemcpy(c->staging, data, n * sizeof(float), hipMemcpyDefault));
         if (s.role == ROLE_REPEAT) HIPCHK(launch_repeat(c->staging, s.dst, (int)n, s.aux, nullptr));
+        else if (s.role == ROLE_KV_HEADS)
+            HIPCHK(launch_repack_heads(c->staging, s.dst, (int)s.shape[0] / (s.aux / 2), s.aux / 2, (int)s.shape[1], s.ld, 2, s.aux & 1, nullptr));
         else HIPCHK(launch_repack_qkv(c->staging, s.dst, (int)s.shape[0] / (3 * s.aux), s.aux, (int)s.shape[1], s.ld, nullptr));
         HIPCHK(hipStreamSynchronize(nullptr));
     } else {
@@ -1333,6 +1376,14 @@ int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up)
     if (res <= 0 || frames <= 0 || tok < 0 || tok >= res * res + 2 * frames * res || ky < 0 || ky > 2 || kx < 0 || kx > 2)
         return fail(MTV_ERR_INVALID, "debug_gather_index: bad arguments") - 1;   // (-2: distinct from "padding")
     return geo_source(res, frames, tok, ky, kx, up != 0);
+}
+
+int mtv_debug_force_lds(int wm, int wn) {
+    if (wm == 0) { g_force_wm = 0; return MTV_OK; }
+    if (!((wm == 2 || wm == 4) && (wn == 2 || wn == 4))) return fail(MTV_ERR_INVALID, "wave tile must be 2 or 4 by 2 or 4");
+    g_force_wm = wm;
+    g_force_wn = wn;
+    return MTV_OK;
 }
 
 int mtv_set_eager(mtv_ctx* c, int eager) {

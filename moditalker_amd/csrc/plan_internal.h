@@ -38,7 +38,8 @@ struct Level {
 // contiguous); QKV_HEADS: a Linear [3*H*d][I] whose rows are (q|k|v, head, d) -> [I][ld] with columns (head, q|k|v, d),
 // the layout k_attention reads (aux = d); REPEAT: every element repeated aux times (a per-channel bias expanded over
 // the aux = patch*patch pixels of a ConvTranspose output)
-enum Role { ROLE_COPY = 0, ROLE_CONV = 1, ROLE_QKV_HEADS = 2, ROLE_REPEAT = 3 };
+enum Role { ROLE_COPY = 0, ROLE_CONV = 1, ROLE_QKV_HEADS = 2, ROLE_REPEAT = 3, ROLE_KV_HEADS = 4 };   // KV_HEADS: a Linear [H*d][I] -> columns
+                                                                                               // (head, k|v, d) of a shared [I][ld] matrix (aux = 2 d + part)
 
 struct WSlot {
     std::string key;
@@ -228,4 +229,5 @@ int finish_split_k(mtv_ctx* c, Plan* p);                   // slab + arrival cou
 int run_ops(mtv_ctx* c, Plan* p, hipStream_t s);
 int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out);
 int check_ready(mtv_ctx* c, int batch);
-int ctx_init_common(mtv_ctx* c);                           // device, capture stream, kernel attributes
+int ctx_init_common(mtv_ctx* c);
+void force_lds_tile(const ConvArgs& a, ConvTile* t);    // MTV_FORCE_LDS testing aid                           // device, capture stream, kernel attributes

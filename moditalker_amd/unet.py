@@ -64,7 +64,8 @@ class UNetModel(nn.Module):
         super().__init__()
         # options the hot path never exercises in the reference
         if use_spatial_transformer or context_dim is not None:
-            raise NotImplementedError("cross-attention conditioning is dormant in the reference (unet.py:470-489) and not built")
+            raise NotImplementedError("SpatialTransformer cannot be constructed in the reference either (its BasicTransformerBlock is "
+                                      "commented out, unet.py:470-489,513); the usable piece, CrossAttention, is moditalker_amd.CrossAttention")
         if dims != 2 or num_classes is not None or use_fp16 or use_new_attention_order or n_embed is not None:
             raise NotImplementedError("only dims=2, fp32, legacy attention order, no class/codebook heads")
         if not resblock_updown:

@@ -297,3 +297,31 @@ def test_module_copies_and_data_writes():
     assert _maxabs(b, (a * 0.5).cpu()) <= 1e-6   # the head conv is linear in (weight, bias)
     net.load_state_dict(twin.state_dict())       # load_state_dict invalidates by itself
     assert torch.equal(net(x, cond, ic, t), a)   # (same context, same plan: bit-equal)
+
+
+@pytest.mark.parametrize("wm,wn", [(2, 4), (4, 2), (4, 4)])
+def test_lds_tiled_conv_kernel_vs_reference_golden(wm, wn):
+    """k_conv_lds (the large-token-count kernel: operands staged in LDS, 2x2 waves per workgroup) forced onto every
+    eligible conv of the base UNet: eps vs the reference golden, and a ragged 2-clip geometry vs the oracle."""
+    from moditalker_amd import _lib
+    from oracle import ref_unet
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_force_lds(wm, wn), "mtv_debug_force_lds")
+    try:
+        g = np.load(os.path.join(GOLDEN, "base.npz"))
+        net = _build(BASE_CFG, 7, max_batch=1)
+        dev = _dev()
+        x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+        for tv in (999, 0):
+            eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
+            assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
+        names = [p["name"] for p in net.diffusion_model.profile_forward(1, 1, dev)]
+        assert sum(",32,1]" in n for n in names) > 100, "the LDS-tiled kernel was not selected"
+        cfg = dict(BASE_CFG, image_size=24)            # 24x24 | 8x24 | 8x24 planes: ragged tiles at every level
+        net2 = _build(cfg, 21, frames=8, max_batch=2)
+        x, cond, ic = filler.synthetic_inputs(2, 24, 8, seed=5, tag="lds")
+        t = torch.tensor([700, 3])
+        ref = ref_unet.unet_forward({k: v.cpu() for k, v in net2.state_dict().items()}, cfg, x, cond, ic, t, 24, 8)
+        assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
+    finally:
+        lib.mtv_debug_force_lds(0, 0)

@@ -125,3 +125,19 @@ def test_autoencoder_oracle_vs_reference_golden(tag, res, B, sub):
     z = ref_ae.extract(sd, vid)
     assert z.shape == (B, 4, L)
     assert float((z - torch.from_numpy(g[f"{tag}_extract"])).abs().max()) <= TOL
+
+
+def test_cross_attention_oracle_vs_reference_golden():
+    from oracle import ref_xattn
+    g = np.load(os.path.join(GOLDEN, "xattn.npz"))
+    for tag, qd, cd, H, d, B, N, M in (("cross", 256, 128, 8, 32, 2, 96, 77), ("self", 128, None, 4, 64, 1, 160, None)):
+        inner = H * d
+        shapes = {"to_q.weight": (inner, qd), "to_k.weight": (inner, cd or qd), "to_v.weight": (inner, cd or qd),
+                  "to_out.0.weight": (qd, inner), "to_out.0.bias": (qd,)}
+        sd = {k: filler.fill_tensor(k, s, 51) for k, s in shapes.items()}
+        x = filler.uniform_pm1(f"xattn.{tag}.x", (B, N, qd), 51)
+        ctx = filler.uniform_pm1(f"xattn.{tag}.ctx", (B, M, cd), 51) if cd else None
+        assert float((ref_xattn.cross_attention(sd, x, ctx, None, H) - torch.from_numpy(g[f"{tag}_out"])).abs().max()) <= 2e-6
+        if cd:
+            mask = torch.from_numpy(g[f"{tag}_mask"])
+            assert float((ref_xattn.cross_attention(sd, x, ctx, mask, H) - torch.from_numpy(g[f"{tag}_out_masked"])).abs().max()) <= 2e-6

@@ -5,11 +5,9 @@
 set -x
 NN=${1:-01}
 cd "$(dirname "$0")/.."
-export TMPDIR=/tmp MTV_TUNE_CACHE=/tmp/mtv_tune_profiles.txt
+export TMPDIR=/tmp
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
-# 1. un-profiled run: auto-tunes every conv shape once and persists the choice, so the profiled processes below
-#    contain only the sampling loop
-timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --batched-clips 0 > /dev/null 2>&1
+# (tiles come from the committed table moditalker_amd/csrc/tune_gfx950.txt: no tuning inside the profiled processes)
 # 2. per-launch hipEvent table (op names / shapes / tiles; also the join key for per_op_rocprof.py)
 timeout 120 python tools/profile_ops.py --iters 20 > $O/r${NN}_per_launch_hipevents.txt 2>$O/ops.err
 # 3. the bench line (N=1, with cpu_baseline and batched_info)
@@ -28,7 +26,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 PF=$(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 PW=$(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
-python tools/summarize_profile.py $KT ${PF:+--fetch $PF} ${PW:+--write $PW} > $O/r${NN}_step_summary.txt 2>&1
+NL=$(grep -m1 -oE '^# [0-9]+ launches' $O/r${NN}_per_launch_hipevents.txt | grep -oE '[0-9]+')
+python tools/summarize_profile.py $KT --launches $NL ${PF:+--fetch $PF} ${PW:+--write $PW} > $O/r${NN}_step_summary.txt 2>&1
 # 6. configs[3] (R=64), informational
 timeout 300 python bench.py --res 64 --steps 40 --warmup 10 --no-cpu-baseline --batched-clips 0 > /dev/null 2>&1
 timeout 300 python bench.py --res 64 --steps 150 --warmup 15 --no-cpu-baseline --batched-clips 0 > $O/r${NN}_bench_res64_n1.json 2>/dev/null

@@ -15,12 +15,22 @@ for l in open(sys.argv[1]):
         ops.append(m.group(1).strip())
 rows = list(csv.DictReader(open(sys.argv[2])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_ddim_update" in r["Kernel_Name"]]
+# a sampler step = len(ops) consecutive dispatches after a k_ddim_init (see summarize_profile.py); the longest run is the timed one
+runs, start = [], None
+for i, r in enumerate(rows):
+    if "k_ddim_init" in r["Kernel_Name"]:
+        start = i + 1
+    elif start is not None and "k_step_sinusoid" in r["Kernel_Name"]:
+        runs.append((start, i))
+        start = None
+if start is not None:
+    runs.append((start, len(rows)))
+s0, s1 = max(runs, key=lambda se: se[1] - se[0])
+n = len(ops)
+idx = [s0 + j * n for j in range((s1 - s0) // n + 1)]
 per = collections.defaultdict(list)
 for a, b in zip(idx[20:-2], idx[21:-1]):
-    ks = [r for r in rows[a + 1:b + 1] if "ddim" not in r["Kernel_Name"]]
-    if len(ks) != len(ops):
-        sys.exit(f"launch count mismatch: {len(ks)} kernels vs {len(ops)} ops")
+    ks = rows[a:b]
     for j, (name, r) in enumerate(zip(ops, ks)):
         per[(j, name)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tab = [(statistics.median(v) / 1e3, k[1]) for k, v in sorted(per.items())]

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Turn a rocprofv3 --kernel-trace CSV of a bench.py run into a per-STEP kernel summary (steady state:
-one DDIM step between two consecutive k_ddim_update dispatches), optionally joined with PMC passes.
-Usage: summarize_profile.py <kernel_trace.csv> [--fetch f_counter_collection.csv] [--write w_counter_collection.csv]"""
+"""Turn a rocprofv3 --kernel-trace CSV of a bench.py run into a per-STEP kernel summary, optionally joined with PMC passes.
+A sampler step is `--launches` consecutive dispatches (the UNet's own launches; bench.py prints the number as
+launches_per_step): the dispatches between a k_ddim_init (end of the sampler set-up) and the next set-up's
+k_step_sinusoid are cut into steps of that length; the longest such run (the timed one) is summarised, steady state only.
+Usage: summarize_profile.py <kernel_trace.csv> --launches N [--fetch f_counter_collection.csv] [--write w_counter_collection.csv]"""
 import argparse
 import collections
 import csv
@@ -13,24 +15,38 @@ def short(name):
     return n
 
 
-def steps_of(rows, key_ts):
+def steps_of(rows, key_ts, n):
+    """-> rows (sorted), list of (first, last+1) row ranges, one per step of the longest sampler run"""
     rows.sort(key=key_ts)
-    idx = [i for i, r in enumerate(rows) if "k_ddim_update" in r["Kernel_Name"]]
-    return rows, idx
+    runs, start = [], None
+    for i, r in enumerate(rows):
+        if "k_ddim_init" in r["Kernel_Name"]:
+            start = i + 1
+        elif start is not None and "k_step_sinusoid" in r["Kernel_Name"]:
+            runs.append((start, i))
+            start = None
+    if start is not None:
+        runs.append((start, len(rows)))
+    # (memcpy nodes are not kernels; anything that is not part of a step -- the final gather's copy kernels -- is cut
+    # off by taking whole multiples of n)
+    best = max(runs, key=lambda se: se[1] - se[0])
+    k = (best[1] - best[0]) // n
+    return rows, [(best[0] + j * n, best[0] + (j + 1) * n) for j in range(k)]
 
 
 ap = argparse.ArgumentParser()
 ap.add_argument("trace")
 ap.add_argument("--fetch")
 ap.add_argument("--write")
-ap.add_argument("--skip", type=int, default=15, help="steps to skip (warm-up / tuning)")
+ap.add_argument("--launches", type=int, required=True, help="dispatches per sampler step (bench.py: launches_per_step)")
+ap.add_argument("--skip", type=int, default=15, help="steps to skip at the start of the run")
 a = ap.parse_args()
-rows, idx = steps_of(list(csv.DictReader(open(a.trace))), lambda r: int(r["Start_Timestamp"]))
-sel = list(zip(idx[a.skip:-1], idx[a.skip + 1:]))
+rows, steps = steps_of(list(csv.DictReader(open(a.trace))), lambda r: int(r["Start_Timestamp"]), a.launches)
+sel = steps[a.skip:-1]
 agg = collections.defaultdict(lambda: [0, 0.0])
 spans, busy = [], []
 for s, e in sel:
-    step = rows[s + 1:e + 1]
+    step = rows[s:e]
     spans.append(int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"]))
     b = 0
     for r in step:
@@ -57,11 +73,11 @@ for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
 for label, path in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
     if not path:
         continue
-    rows2, idx2 = steps_of(list(csv.DictReader(open(path))), lambda r: int(r["Dispatch_Id"]))
-    sel2 = list(zip(idx2[5:-1], idx2[6:]))
+    rows2, steps2 = steps_of(list(csv.DictReader(open(path))), lambda r: int(r["Dispatch_Id"]), a.launches)
+    sel2 = steps2[5:-1]
     fam2 = collections.defaultdict(float)
     for s, e in sel2:
-        for r in rows2[s + 1:e + 1]:
+        for r in rows2[s:e]:
             k = short(r["Kernel_Name"])
             f = "k_conv<*>" if k.startswith("k_conv") else ("k_attention<*>" if k.startswith("k_attention") else k)
             fam2[f] += float(r["Counter_Value"])
