@@ -94,12 +94,11 @@ struct WalkCtx {
     int i;
 };
 
-template <int MT, int NT, int ROWS>
-__device__ __forceinline__ void load_chunk(const WalkCtx& w, int ch, Raw<MT, NT>& o) {
-    const ChunkRec* rp = w.recs + (ch - w.wg_ch0);
-    const unsigned a_lo = (unsigned)usgpr((int)rp->a_lo), a_hi = (unsigned)usgpr((int)rp->a_hi);
-    const unsigned wrow = (unsigned)usgpr((int)rp->wrow), meta = (unsigned)usgpr((int)rp->meta);
-    const int tap = (int)((meta >> 24) & 15u), skip = (int)(meta >> 28);
+// issue the loads of one chunk: W fragment rows wrow .. wrow+15, A rows given by the source-token entries e[]
+template <int MT, int NT>
+__device__ __forceinline__ void issue_chunk(const WalkCtx& w, unsigned a_lo, unsigned a_hi, unsigned wrow, unsigned meta, const int (&e)[MT],
+                                            Raw<MT, NT>& o) {
+    const int skip = (int)(meta >> 28);
     const unsigned Cp4 = ((meta >> 16) & 0xFFu) << 6;            // bytes per source row of this part
     o.cc = (int)(meta & 0xFFFFu);
     o.skip = skip;
@@ -124,13 +123,61 @@ __device__ __forceinline__ void load_chunk(const WalkCtx& w, int ch, Raw<MT, NT>
     const unsigned bl = skip ? w.bL[1] : w.bL[0];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int e = w.idx[tap * ROWS + 16 * mt + w.i];
-        o.e[mt] = e;
-        const unsigned st = e < 0 ? 0u : (unsigned)(e & 0x0FFFFFFF);   // padded rows read a valid address, zeroed later
+        o.e[mt] = e[mt];
+        const unsigned st = e[mt] < 0 ? 0u : (unsigned)(e[mt] & 0x0FFFFFFF);   // padded rows read a valid address, zeroed later
         const unsigned rowoff = (bl + st) * Cp4 + w.q16;
         if constexpr (MTV_ABLATE & 2) o.a[mt] = f32x4{1.f, 2.f, 3.f, 4.f};
         else o.a[mt] = *(const __attribute__((address_space(1))) f32x4*)(abase + rowoff);
     }
+}
+
+// chunk `ch` through the LDS tables (record + row table)
+template <int MT, int NT, int ROWS>
+__device__ __forceinline__ void load_chunk(const WalkCtx& w, int ch, Raw<MT, NT>& o) {
+    const ChunkRec* rp = w.recs + (ch - w.wg_ch0);
+    const unsigned a_lo = (unsigned)usgpr((int)rp->a_lo), a_hi = (unsigned)usgpr((int)rp->a_hi);
+    const unsigned wrow = (unsigned)usgpr((int)rp->wrow), meta = (unsigned)usgpr((int)rp->meta);
+    const int tap = (int)((meta >> 24) & 15u);
+    int e[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) e[mt] = w.idx[tap * ROWS + 16 * mt + w.i];
+    issue_chunk<MT, NT>(w, a_lo, a_hi, wrow, meta, e, o);
+}
+
+// the record of chunk `ch` from the launch arguments alone (what the table builder stores in LDS)
+__device__ __forceinline__ ChunkRec chunk_record(const ConvArgs& a, int ch) {
+    const int nmainch = a.ntaps * a.cpt, Cmain = a.Cmain;
+    const bool skip = ch >= nmainch;
+    const int tap = skip ? a.ntaps : fdiv(ch, a.cpt, a.inv_cpt);
+    const int w = skip ? ch - nmainch : ch - tap * a.cpt;
+    const int c0_16 = (skip ? a.C[2] : a.C[0]) >> 4;
+    const bool second = w >= c0_16;                            // second part of a channel concatenation
+    const int c = (second ? w - c0_16 : w) << 4;
+    const float* sp = skip ? (second ? a.src[3] : a.src[2]) : (second ? a.src[1] : a.src[0]);
+    const int Cp = skip ? (second ? a.C[3] : a.C[2]) : (second ? a.C[1] : a.C[0]);
+    const int coff = second ? (skip ? a.C[2] : a.C[0]) : 0;
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(sp) + (unsigned long long)c * 4ull;
+    ChunkRec r;
+    r.a_lo = (unsigned)(ab & 0xFFFFFFFFull);
+    r.a_hi = (unsigned)(ab >> 32);
+    r.wrow = (unsigned)((skip ? a.ntaps * Cmain : tap * Cmain) + coff + c);
+    r.meta = (unsigned)(coff + c) | ((unsigned)(Cp >> 4) << 16) | ((unsigned)tap << 24) | ((unsigned)(skip ? 1 : 0) << 28);
+    return r;
+}
+
+// the row-table entry of (tap t, output token tok): source token | plane << 28, -1 = zero padding / past the end
+__device__ __forceinline__ int row_entry(const ConvArgs& a, int t, int tok) {
+    if (tok >= a.Lout) return -1;
+    if (t < a.ntaps) {
+        if (a.geo_main) {
+            const int ky = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
+            return geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, ky, t - 3 * ky, a.geo_main == 2);
+        }
+        const int st = a.gather ? a.gather[t * a.Lout + tok] : tok;
+        return st < 0 ? -1 : (st | (seg_of(a.seg_src, st) << 28));
+    }
+    if (a.geo_skip) return geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF;
+    return a.gather_skip ? a.gather_skip[tok] : tok;
 }
 
 // coef holds, per (plane, channel), the folded affine {A, B}: y = x*A + B with A = gn_scale*(1+film_scale),
@@ -277,62 +324,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     int* idx = reinterpret_cast<int*>(smem + a.rec_cap * 4);
     const int idx_floats = ((a.ntaps + 1) * ROWS + 3) & ~3;
     float2* coef = reinterpret_cast<float2*>(smem + a.rec_cap * 4 + idx_floats);
-    {
-        const int nmainch = a.ntaps * a.cpt;
-        for (int e = tid; e < wg_ch1 - wg_ch0; e += NTH) {
-            const int ch = wg_ch0 + e;
-            const bool skip = ch >= nmainch;
-            const int tap = skip ? a.ntaps : fdiv(ch, a.cpt, a.inv_cpt);
-            const int w = skip ? ch - nmainch : ch - tap * a.cpt;
-            const int c0_16 = (skip ? a.C[2] : a.C[0]) >> 4;
-            const bool second = w >= c0_16;                            // second part of a channel concatenation
-            const int c = (second ? w - c0_16 : w) << 4;
-            const float* sp = skip ? (second ? a.src[3] : a.src[2]) : (second ? a.src[1] : a.src[0]);
-            const int Cp = skip ? (second ? a.C[3] : a.C[2]) : (second ? a.C[1] : a.C[0]);
-            const int coff = second ? (skip ? a.C[2] : a.C[0]) : 0;
-            const unsigned long long ab = reinterpret_cast<unsigned long long>(sp) + (unsigned long long)c * 4ull;
-            ChunkRec r;
-            r.a_lo = (unsigned)(ab & 0xFFFFFFFFull);
-            r.a_hi = (unsigned)(ab >> 32);
-            r.wrow = (unsigned)((skip ? a.ntaps * Cmain : tap * Cmain) + coff + c);
-            r.meta = (unsigned)(coff + c) | ((unsigned)(Cp >> 4) << 16) | ((unsigned)tap << 24) | ((unsigned)(skip ? 1 : 0) << 28);
-            recs[e] = r;
-        }
-    }
-    // source-token table: identity, arithmetic (geo_source) or -- only if the host check of the formula ever failed
-    // -- the gather tables in global memory.  Complete before the first barrier, so every wave's operand ring starts
-    // right after it.
-    auto skip_src = [&](int tok) -> int {
-        if (a.geo_skip) return geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF;
-        return a.gather_skip ? a.gather_skip[tok] : tok;
-    };
-    // (the row table is built by the LAST threads of the workgroup, the chunk records above by the first ones: in an
-    // 8-wave workgroup no wave executes both, which halves the instructions on this serial stretch)
-    for (int e = NTH - 1 - tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
-        const int t = e / ROWS, r = e - t * ROWS;
-        const int tok = tok0 + r;
-        int v = -1;
-        if (tok < a.Lout) {
-            if (t < a.ntaps) {
-                if (a.geo_main) {
-                    const int ky = t >= 6 ? 2 : (t >= 3 ? 1 : 0);
-                    v = geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, ky, t - 3 * ky, a.geo_main == 2);
-                } else {
-                    const int st = a.gather ? a.gather[t * a.Lout + tok] : tok;
-                    v = st < 0 ? -1 : (st | (seg_of(a.seg_src, st) << 28));
-                }
-            } else {
-                v = skip_src(tok);
-            }
-        }
-        idx[e] = v;
-    }
-    MTV_STAMP(8);
-    __syncthreads();
-    MTV_STAMP(9);
-
-    // ---- this wave's chunk range; its whole operand ring (A and W) is requested NOW, so the (HBM-cold) weight
-    // latency overlaps the rest of the prologue
+    // ---- this wave's chunk range.  Its FIRST chunk is requested right away, straight from the launch arguments
+    // (record and row entries computed in registers): the first -- HBM-cold -- round trip starts before the tables
+    // are built instead of after them.
     const int slice = slice0 + wave;
     const int ch0 = slice * a.cps_q + min(slice, a.cps_r);
     const int ch1 = ch0 + a.cps_q + (slice < a.cps_r ? 1 : 0);
@@ -351,12 +345,34 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     constexpr int DEPTH = NW == 16 ? (MT * NT >= 4 ? 2 : (MT * NT >= 2 ? 3 : 4)) : (MT * NT >= 16 ? 2 : (MT * NT >= 8 ? 3 : 4));
     Raw<MT, NT> ring[DEPTH];
     int nx = ch0;                                       // next chunk to request
+    if (ch0 < ch1) {
+        const ChunkRec r0 = chunk_record(a, ch0);
+        const unsigned m0 = (unsigned)usgpr((int)r0.meta);
+        const int tap0 = (int)((m0 >> 24) & 15u);
+        int e0[MT];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
+        for (int mt = 0; mt < MT; ++mt) e0[mt] = row_entry(a, tap0, tok0 + 16 * mt + i);
+        issue_chunk<MT, NT>(wc, (unsigned)usgpr((int)r0.a_lo), (unsigned)usgpr((int)r0.a_hi), (unsigned)usgpr((int)r0.wrow), m0, e0, ring[0]);
+        ++nx;
+    }
+    MTV_STAMP(10);
+    for (int e = tid; e < wg_ch1 - wg_ch0; e += NTH) recs[e] = chunk_record(a, wg_ch0 + e);
+    // source-token table: identity, arithmetic (geo_source) or -- only if the host check of the formula ever failed
+    // -- the gather tables in global memory.  (Built by the LAST threads of the workgroup, the chunk records above by
+    // the first ones: in an 8-wave workgroup no wave executes both, which halves the instructions on this stretch.)
+    for (int e = NTH - 1 - tid; e < (a.ntaps + 1) * ROWS; e += NTH) {
+        const int t = e / ROWS, r = e - t * ROWS;
+        idx[e] = row_entry(a, t, tok0 + r);
+    }
+    MTV_STAMP(8);
+    __syncthreads();
+    MTV_STAMP(9);
+    // the rest of the operand ring, through the tables
+#pragma unroll
+    for (int d = 1; d < DEPTH; ++d)
         if (d < ch1 - ch0) {
             load_chunk<MT, NT, ROWS>(wc, nx, ring[d]);
             ++nx;
-            if (d == 0) MTV_STAMP(10);
         }
 
     DdimStep stp{};
@@ -637,7 +653,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             // a sub-ulp reassociation of the bias terms only
             v = (v + pre_bias) + pre_res;
         } else {
-            const int rs = a.res ? skip_src(tok) : tok;   // (the LDS index table is gone by now)
+            const int rs = a.res ? row_entry(a, a.ntaps, tok) : tok;   // (the LDS index table is gone by now)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (n + k < a.N) v[k] = epi(a, v[k], b, tok, rs, n + k);

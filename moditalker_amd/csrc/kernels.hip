@@ -307,10 +307,16 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
                 for (int e = 0; e < VW; ++e) s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[e], qreg[u][e], s4, 0, 0, 0);
             }
             if constexpr (!FULL) {
+                // keys past the end of the segment, or masked out by the caller (unet.py:452-456), score -inf.  Branch-free:
+                // the mask bytes are fetched with a clamped index and folded into a select (the short-circuit form
+                // `key >= klen || (kmask && !kmask[key])` lost the mask term in hipcc 7.2's control-flow lowering)
+                const int key0 = kb + kt * 16 + 4 * g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kb + kt * 16 + 4 * g + r;
-                    if (key >= klen || (kmask && !kmask[key])) s4[r] = -INFINITY;     // past the end, or masked out (unet.py:452-456)
+                    const bool oob = key0 + r >= klen;
+                    unsigned mv = 1u;
+                    if (kmask) mv = kmask[oob ? 0 : key0 + r];
+                    s4[r] = (oob || mv == 0u) ? -INFINITY : s4[r];
                 }
             }
             st[w] = s4;

@@ -7,5 +7,7 @@ export MTV_TUNE_CACHE=$PWD/gpurun_out/tune_raw.txt
 rm -f $MTV_TUNE_CACHE; mkdir -p gpurun_out
 timeout 600 python bench.py --steps 20 --warmup 2 --ramp-steps 5 --no-cpu-baseline --batched-clips 8 > /dev/null
 timeout 600 python bench.py --res 64 --steps 10 --warmup 2 --ramp-steps 5 --no-cpu-baseline --batched-clips 0 > /dev/null
+timeout 300 python tools/ae_profile.py > /dev/null                  # the autoencoder's GEMM shapes (decode, then extract)
+timeout 300 python tools/ae_profile.py --extract > /dev/null
 (echo "# conv shape -> measured best tile (MT NT NW KS XM); regenerate with tools/make_tune_table.sh on an MI355X"; sort -u $MTV_TUNE_CACHE) > gpurun_out/tune_gfx950.txt
 wc -l gpurun_out/tune_gfx950.txt
