@@ -69,6 +69,8 @@ def main():
                     help="untimed denoising steps run BEFORE the warm-up so that plan build, tile tuning, graph capture and the "
                          "GPU's clock ramp (DVFS: a cold MI355X runs its first ~100 ms well below its sustained clock) all "
                          "happen outside the timed region; set-up, not steps")
+    ap.add_argument("--no-autoencoder", action="store_true",
+                    help="skip the informational autoencoder timings (decode_from_sample / extract of one 16-frame 256x256 clip)")
     ap.add_argument("--res", type=int, default=32, choices=(32, 64),
                     help="latent resolution R: 32 = BASELINE configs[1] (the metric's workload), 64 = configs[3] (512x512 clip)")
     args = ap.parse_args()
@@ -302,6 +304,39 @@ def main():
                            k_attention_tflops=round(afl / ams / 1e9, 2),
                            k_attention_frac_of_f32_mfma_peak=round(afl / ams / 1e9 / MFMA_F32_PEAK_TF, 3))
             del netb, dmb
+        # ---- informational only: the steps either side of the loop (BASELINE configs[4]'s decode tail, section 8 f-1/f-2),
+        # one 16-frame 256x256 clip through the HIP autoencoder (recipe-filled weights; never part of `value`)
+        ae_info = None
+        if world == 1 and not args.no_autoencoder and R == 32:
+            from moditalker_amd import BASE_AE_DDCONFIG, ViTAutoencoder
+            from moditalker_amd import filler
+            ae = ViTAutoencoder(4, BASE_AE_DDCONFIG).eval()
+            filler.fill_autoencoder_(ae, seed=77)       # arithmetic recipe; output layers kept out of saturation
+            ae = ae.to(dev)
+            zlat = xt.clone()
+            vid = torch.rand(1, 3, 16, 256, 256, generator=g, device=dev) * 2 - 1
+
+            def timed(fn, n=5):
+                fn()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t1) / n
+
+            t_dec = timed(lambda: ae.decode_from_sample(zlat))
+            t_ext = timed(lambda: ae.extract(vid))
+            pd = ae.profile(1, False, 2)
+            gfl = sum(p["flops"] for p in pd if p["name"].startswith("gemm"))
+            gms = sum(p["ms"] for p in pd if p["name"].startswith("gemm"))
+            ae_info = dict(decode_from_sample_ms=round(1e3 * t_dec, 3), extract_ms=round(1e3 * t_ext, 3), launches_decode=len(pd),
+                           decode_tflop=round(sum(p["flops"] for p in pd) / 1e12, 3),
+                           gemm_tflops=round(gfl / gms / 1e9, 1) if gms else None,
+                           gemm_frac_of_f32_mfma_peak=round(gfl / gms / 1e9 / MFMA_F32_PEAK_TF, 3) if gms else None,
+                           clip_end_to_end_ms_at_250_steps=round(250 * 1e3 * dt / K + 1e3 * (t_dec + 4 * t_ext), 1),
+                           note="4 extracts + 250 steps + decode per 16-frame clip (sample.py:328-386); weights random-init")
+            del ae
         attn_roof = dict(bound="mfma", kernel="k_attention", achieved=round(attn["flops"] / (attn["ms"] * 1e-3) / 1e12, 3) if attn["ms"] else 0.0,
                          peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches_per_step=attn["launches"], flops_per_step=attn["flops"])
         attn_roof["frac"] = round(attn_roof["achieved"] / MFMA_F32_PEAK_TF, 4)
@@ -330,6 +365,7 @@ def main():
             "families": families,
             "roofline_attention": attn_roof,
             "batched_info": batched,
+            "autoencoder_info": ae_info,
         }
     barrier()
     if rank == 0:

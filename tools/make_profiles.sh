@@ -18,10 +18,11 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt 
 KT=$(find $O/kt -name '*kernel_trace.csv' | head -1)
 cp "$(find $O/kt -name '*kernel_stats.csv' | head -1)" $O/r${NN}_rocprofv3_kernel_stats.csv
 python tools/per_op_rocprof.py $O/r${NN}_per_launch_hipevents.txt $KT $O/r${NN}_per_op_rocprof.txt > /dev/null 2>&1
-# 5. PMC passes, each in its own run, kernel trace only (never combined with hip/hsa/sys trace domains)
+# 5. PMC passes, each in its own run, kernel trace only (never combined with hip/hsa/sys trace domains).  MTV_EAGER=1: the
+#    same launches as plain launches -- rocprofv3 --pmc segfaults at the first hipGraph replay of the round-2 step graph
 for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- \
-        python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 > $O/pmc_$c.log 2>&1
+    MTV_EAGER=1 timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- \
+        python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_$c.log 2>&1
     echo "pmc $c rc=$?"
 done
 PF=$(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
@@ -31,5 +32,14 @@ python tools/summarize_profile.py $KT --launches $NL ${PF:+--fetch $PF} ${PW:+--
 # 6. configs[3] (R=64), informational
 timeout 300 python bench.py --res 64 --steps 40 --warmup 10 --no-cpu-baseline --batched-clips 0 > /dev/null 2>&1
 timeout 300 python bench.py --res 64 --steps 150 --warmup 15 --no-cpu-baseline --batched-clips 0 > $O/r${NN}_bench_res64_n1.json 2>/dev/null
-rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+# 7. the autoencoder steps either side of the loop (informational): per-launch tables + rocprofv3 kernel stats of decode
+timeout 300 python tools/ae_profile.py > $O/r${NN}_ae_decode_per_launch.txt 2>/dev/null
+timeout 300 python tools/ae_profile.py --extract > $O/r${NN}_ae_extract_per_launch.txt 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktae -o kt -- python tools/ae_profile.py > /dev/null 2>&1
+cp "$(find $O/ktae -name '*kernel_stats.csv' | head -1)" $O/r${NN}_ae_decode_rocprofv3_kernel_stats.csv
+# 8. the in-kernel phase anatomy of every conv of a step (diagnostic build with s_memtime stamps)
+MTV_LIB=$PWD/moditalker_amd/csrc/libmtv_hip_stamp.so MTV_STAMPS=1 timeout 300 python tools/stamps.py > $O/r${NN}_conv_phase_stamps.txt 2>/dev/null
+# 9. the launch-chain microbenchmark
+timeout 120 tools/ubench/chain > $O/r${NN}_launch_chain_ubench.txt 2>&1
+rm -rf $O/kt $O/ktae $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 tail -25 $O/r${NN}_step_summary.txt
