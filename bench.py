@@ -368,10 +368,16 @@ def main():
             "autoencoder_info": ae_info,
         }
     barrier()
-    if rank == 0:
-        print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, buffered until exit
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -151,3 +151,32 @@ def test_two_chunk_chained_run_vs_oracle(tmp_path):
         d = np.abs(a.astype(np.int32) - b.astype(np.int32))
         assert d.max() <= 2 and d.mean() <= 0.05, (int(d.max()), float(d.mean()))
     assert len(os.listdir(tmp_path / "frames")) == 2 * T and (tmp_path / "references" / "16" / "0.png").exists()
+
+
+def test_config4_full_size_sampler_then_decode_vs_oracle():
+    """BASELINE configs[4] at its own geometry: base second-stage UNet on a 16-frame 256x256 clip's latent [1,4,2048]
+    (R=32, T=16), DDIM sampler -> RGB autoencoder decode_from_sample at 256x256 -> clamp -> frames, HIP against the CPU
+    oracle on identical weights / inputs / noise.  (4 DDIM steps keep the oracle side at ~15 s; the 250-step schedule is
+    pinned by test_base_sampler_vs_reference_golden, the 256^2 decode by test_decode_from_sample_vs_reference_golden.)"""
+    from conftest import BASE_CFG
+    from oracle import ref_ae, ref_ddpm, ref_unet
+    dev = _dev()
+    R, T, S = 32, 16, 4
+    net = DiffusionWrapper(UNetModel(**BASE_CFG, frames=T, max_batch=1)).eval()
+    filler.fill_module_(net, seed=7, skip_prefixes=("output_bg_",))
+    sd_u = {k: v.clone() for k, v in net.state_dict().items() if "output_bg_" not in k}
+    net = net.to(dev)
+    ae = _ae(256, 22)
+    sd_a = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
+    L = R * R + 2 * T * R
+    x, cond, ic = filler.synthetic_inputs(1, R, T, seed=7, tag="base")
+    noise = filler.noise_list(S, (1, 4, L), seed=7, tag="cfg4.noise")
+    dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+    z = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=[n.to(dev) for n in noise])
+    frames = ae.decode_from_sample(z).clamp(-1, 1).cpu()
+    zr = ref_ddpm.ddim_sample(lambda a, b, c, d: ref_unet.unet_forward(sd_u, BASE_CFG, a, b, c, d, R, T), cond, ic, noise, S)
+    fr = ref_ae.decode_from_sample(sd_a, zr, 256, T).clamp(-1, 1)
+    assert frames.shape == (16, 3, 256, 256)
+    assert float((z.cpu() - zr).abs().max()) <= TOL
+    mse = float(((frames - fr) ** 2).mean())
+    assert mse <= 1e-8 and float((frames - fr).abs().max()) <= TOL, (mse, float((frames - fr).abs().max()))
