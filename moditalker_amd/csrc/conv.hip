@@ -519,7 +519,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         for (int e = tid; e < 3 * (COLS / 4) * 2; e += NTH) qs[e] = 0.0;
     constexpr int TILE_REGS = MT * NT * 4;
     constexpr int LDR = COLS + 4;
-    constexpr bool ONE_STAGE = NW > 1 && NW * TILE_REGS * 64 * 4 <= 48 * 1024;   // all partials fit in LDS at once
+    constexpr int WTILE = ROWS * LDR;            // floats of one wave's partial tile as a (row, col) image (ONE_STAGE)
+    constexpr bool ONE_STAGE = NW > 1 && NW * WTILE * 4 <= 48 * 1024;   // all partials fit in LDS at once
     if constexpr (NW == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -529,14 +530,19 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
                 for (int nb = 0; nb < NT; ++nb) red[(16 * mt + 4 * q + r) * LDR + NT * i + nb] = acc[mt][nb][r];
         __syncthreads();
     } else if constexpr (ONE_STAGE) {
-        // every wave parks its partial tile (lane-linear image: conflict-free); pass 1 sums them in wave order
-        float* my = red + (size_t)wave * TILE_REGS * 64 + lane;
+        // every wave parks its partial tile as a (row, col) image: lane (i, q) holds, for row 4q + r, the NT consecutive
+        // columns NT i .. -> one 16-byte (8-, 4-byte) store per (row block, r), and pass 1 reads one 16-byte quad per wave
+        // (the earlier lane-linear image cost 16 scalar stores and 4 NW scalar loads per thread)
+        float* my = red + (size_t)wave * WTILE + (4 * q) * LDR + NT * i;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nb = 0; nb < NT; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) my[((mt * NT + nb) * 4 + r) * 64] = acc[mt][nb][r];
+            for (int r = 0; r < 4; ++r) {
+                float* dstp = my + (16 * mt + r) * LDR;
+                if constexpr (NT == 4) *reinterpret_cast<f32x4*>(dstp) = f32x4{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                else if constexpr (NT == 2) *reinterpret_cast<f32x2*>(dstp) = f32x2{acc[mt][0][r], acc[mt][1][r]};
+                else dstp[0] = acc[mt][0][r];
+            }
         __syncthreads();
     } else {
 #pragma unroll
@@ -577,19 +583,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     // ---- pass 1 (row-major over the tile): epilogue + coalesced store
     constexpr int QPR = COLS / 4, QUADS = ROWS * QPR;
     const bool want_stats = a.nstat > 0;
-    float* fin = ONE_STAGE ? red + (size_t)NW * TILE_REGS * 64 : red;   // (row, col) image of the finished tile for pass 2
+    float* fin = ONE_STAGE ? red + (size_t)NW * WTILE : red;   // (row, col) image of the finished tile for pass 2
     auto tile_quad = [&](int rr, int cq) -> f32x4 {                     // this workgroup's (partial) result for one quad
         if constexpr (ONE_STAGE) {
-            // element (rr, 4cq+k) of wave w sits at w*TILE + ((mt*NT+nb)*4 + r)*64 + lane(i, q)
-            const int mt = rr >> 4, qq = (rr >> 2) & 3, r = rr & 3;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            // fixed order over the waves (run-to-run bit-equal)
+            f32x4 v = *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
 #pragma unroll
-            for (int w = 0; w < NW; ++w)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int col = cq * 4 + k, ii = col / NT, nb = col - ii * NT;
-                    v[k] += red[(size_t)w * TILE_REGS * 64 + ((mt * NT + nb) * 4 + r) * 64 + qq * 16 + ii];
-                }
+            for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(red + (size_t)w * WTILE + rr * LDR + cq * 4);
             return v;
         } else {
             return *reinterpret_cast<const f32x4*>(red + rr * LDR + cq * 4);
@@ -1097,10 +1097,10 @@ static size_t lds_bytes(int MT, int NT, int NW, int KS, int ntaps, int Cmain, in
     const int nchunks = ntaps * (Cmain / 16) + Cskip / 16;
     const size_t idx = (size_t)(((ntaps + 1) * ROWS + 3) & ~3) * 4 + (size_t)rec_capacity(nchunks, NW, KS) * 16;
     const size_t coef = has_gn ? (size_t)24 * Cmain : 0;
-    const size_t part = (size_t)MT * NT * 4 * 64 * 4;                 // one wave's partial tile
-    const size_t fin = (size_t)ROWS * (COLS + 4) * 4;                 // finished tile
-    const bool one_stage = NW > 1 && NW * part <= 48 * 1024;
-    const size_t redu = one_stage ? NW * part + fin : ((size_t)(NW / 2) * part > fin ? (size_t)(NW / 2) * part : fin);
+    const size_t part = (size_t)MT * NT * 4 * 64 * 4;                 // one wave's partial tile, lane-linear (tree reduction)
+    const size_t fin = (size_t)ROWS * (COLS + 4) * 4;                 // a (row, col) tile image: finished tile / ONE_STAGE partial
+    const bool one_stage = NW > 1 && NW * fin <= 48 * 1024;
+    const size_t redu = one_stage ? NW * fin + fin : ((size_t)(NW / 2) * part > fin ? (size_t)(NW / 2) * part : fin);
     size_t r = idx + coef;
     if (redu > r) r = redu;
     r = (r + 15) & ~(size_t)15;
