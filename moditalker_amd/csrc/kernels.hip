@@ -180,7 +180,10 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     constexpr int VW = D >= 16 ? 4 : D / 4;        // floats per q/k fragment
     constexpr int NV = D >= 16 ? D / 16 : 1;       // fragments per row
     constexpr int NOB = D >= 16 ? D / 16 : 1;      // 16-row output blocks of O^T
-    constexpr int KSTR = D + (D >= 32 ? 4 : 0);    // K row stride in LDS (floats)
+    // K row stride in LDS (floats): rows + 4 so that the 16 lanes of a 16-byte fragment read (rows j = 0..15, same quad g)
+    // hit 16 distinct bank quads -- (KSTR/4 * j + g) mod 16 must be a permutation of j: KSTR/4 odd.  (D = 16 ran unpadded
+    // through round 2's first half: stride 16 floats = a 4-way conflict on every K fragment of the level-0 attentions.)
+    constexpr int KSTR = D + (D >= 16 ? 4 : 0);
     constexpr int KB = D >= 128 ? 16 : (D >= 64 ? 32 : (D >= 32 ? 64 : 128));   // keys per block (LDS budget)
     constexpr int NKT = KB / 16;                   // 16-key tiles per block
     constexpr int WKT = NKT / KSP;                 // ... of which each wave takes WKT
@@ -202,21 +205,24 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     // which (segment, 64-query block)
     // 1-D grid, head fastest: consecutive workgroup ids go round-robin over the 8 XCDs, so with H = 8 every
     // workgroup of a head runs on the same XCD and the head's K/V rows are fetched into ONE L2 (speed only).
-    const int h = blockIdx.x % a.H;
-    const int rest = blockIdx.x / a.H;
-    const int nblk = a.blk_prefix[a.nseg];
-    const int qblk = rest % nblk, b = rest / nblk;
-    int sg = 0, q0, start, len;
-    if (a.seg_uniform) {                            // equal segments: segment = qblk / blocks per segment
-        sg = qblk / a.bps;
-        len = a.seg_uniform;
-        start = sg * len;
-        q0 = (qblk - sg * a.bps) * (16 * QW) + qw * 16;
-    } else {
-        while (sg + 1 < a.nseg && qblk >= a.blk_prefix[sg + 1]) ++sg;
-        q0 = (qblk - a.blk_prefix[sg]) * (16 * QW) + qw * 16;
-        start = a.seg_start[sg];
-        len = a.seg_len[sg];
+    // (all divisions by float reciprocals from the host: exact below 2^22, which launch_attention checks; the decode is
+    // branch-free so that every argument is fetched at entry -- a loop over blk_prefix made the compiler fetch and wait
+    // for one kernel argument at a time)
+    const int rest = FDiv{a.inv_H}((int)blockIdx.x, a.H);
+    const int h = (int)blockIdx.x - rest * a.H;
+    const int nblk = a.blk_prefix[3];               // (host: unused prefix slots hold the total)
+    const int b = FDiv{a.inv_nblk}(rest, nblk);
+    const int qblk = rest - b * nblk;
+    int sg, q0, start, len;
+    {
+        const int su = FDiv{a.inv_bps}(qblk, a.bps);                                        // uniform: segment = qblk / blocks per segment
+        const int sn = (qblk >= a.blk_prefix[1] ? 1 : 0) + (qblk >= a.blk_prefix[2] ? 1 : 0);
+        const bool uni = a.seg_uniform != 0;
+        sg = uni ? su : sn;
+        const int first = uni ? su * a.bps : (sn == 0 ? 0 : (sn == 1 ? a.blk_prefix[1] : a.blk_prefix[2]));
+        len = uni ? a.seg_uniform : (sn == 0 ? a.seg_len[0] : (sn == 1 ? a.seg_len[1] : a.seg_len[2]));
+        start = uni ? su * a.seg_uniform : (sn == 0 ? a.seg_start[0] : (sn == 1 ? a.seg_start[1] : a.seg_start[2]));
+        q0 = (qblk - first) * (16 * QW) + qw * 16;
     }
     // self-attention: q | k | v of a head are adjacent in ONE buffer (row stride 3C).  Cross-attention (a.kv != nullptr,
     // CrossAttention of unet.py:429-467): queries [B][L][C] (head-major), keys/values in a second buffer [B][Lkv][2C] with
@@ -235,14 +241,15 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         __syncthreads();
     }
 
-    float qreg[NV][VW];
+    // q fragments: UNCONDITIONAL vector loads from a clamped row (a conditional scalar load per element compiled to 16
+    // branches with a full wait each), requested together with the first K/V tile; masked when they are consumed
+    typedef float qvec_t __attribute__((ext_vector_type(VW)));
+    qvec_t qraw[NV];
+    const bool qok = q0 + j < len;
     {
-        const bool ok = q0 + j < len;
-        const float* qp = base + (size_t)(start + (ok ? q0 + j : 0)) * RS + VW * g;
+        const float* qp = base + (size_t)(start + (qok ? q0 + j : 0)) * RS + VW * g;
 #pragma unroll
-        for (int u = 0; u < NV; ++u)
-#pragma unroll
-            for (int e = 0; e < VW; ++e) qreg[u][e] = ok ? qp[16 * u + e] * scale * LOG2E : 0.f;   // scores in log2 units
+        for (int u = 0; u < NV; ++u) qraw[u] = *reinterpret_cast<const qvec_t*>(qp + 16 * u);
     }
     f32x4 oacc[NOB];
 #pragma unroll
@@ -256,56 +263,94 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         for (int r = 0; r < NLD; ++r) {
             const int e = tid + NTH * r;
             const int key = e / QPR, qd = e - key * QPR;
+            // (e >= KB * QPR only in the last, partial r: then key >= KB, the row is clamped and qd stays < QPR)
             const bool ok = e < KB * QPR && kb + key < klen;
             const float* p = kbase + (size_t)(kstart + (ok ? kb + key : 0)) * RSK + qd * 4;
-            kreg[r] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
-            vreg[r] = ok ? *reinterpret_cast<const f32x4*>(p + D) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // unconditional loads, RAW registers: rows past the segment are zeroed when the tile is written to LDS -- a
+            // select here puts the wait for the loads right behind their issue, i.e. in front of the block's math
+            kreg[r] = *reinterpret_cast<const f32x4*>(p);
+            vreg[r] = *reinterpret_cast<const f32x4*>(p + D);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int kb) {
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
             const int e = tid + NTH * r;
             const int key = e / QPR, qd = e - key * QPR;
             if (e < KB * QPR) {
-                *reinterpret_cast<f32x4*>(&Ks[buf][key * KSTR + qd * 4]) = kreg[r] * scale;
+                const bool in = kb + key < klen;
+                *reinterpret_cast<f32x4*>(&Ks[buf][key * KSTR + qd * 4]) = in ? kreg[r] * scale : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) Vt[buf][(qd * 4 + c) * VSTR + key] = vreg[r][c];
+                for (int c = 0; c < 4; ++c) Vt[buf][(qd * 4 + c) * VSTR + key] = in ? vreg[r][c] : 0.f;
             }
         }
     };
 
     gload(0);
-    lstore(0);
+    float qreg[NV][VW];
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) qreg[u][e] = qok ? qraw[u][e] * scale * LOG2E : 0.f;   // scores in log2 units
+    lstore(0, 0);
     __syncthreads();
     int buf = 0;
     // One key block.  FULL (every key of the block exists -- all blocks but possibly the last) is a separate
     // instantiation: no per-element masking, no all-masked guard.  Scores are in the log2 domain (log2 e is
     // folded into q), so p = exp2(s - m) is one subtract + one v_exp_f32 per element; the cross-lane maxima
     // use the gfx950 lane-swap instructions (VALU, no LDS round trip).
-    auto block = [&](int kb, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    auto block = [&](int kb, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;       // 0: every key exists; 1: partial block; 2: caller's key mask
+        constexpr bool FULL = MODE == 0;
         const float* ks = Ks[buf];
         const float* vt = Vt[buf];
         f32x4 st[WKT];
+        unsigned mv[WKT][4];
+        if constexpr (MODE == 2) {      // all mask bytes of the wave's tiles requested together, ahead of the QK^T MFMAs
+#pragma unroll
+            for (int w = 0; w < WKT; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + (kh * WKT + w) * 16 + 4 * g + r;
+                    mv[w][r] = kmask[key >= klen ? 0 : key];
+                }
+        }
+        // S^T tiles.  A dependent v_mfma_f32_16x16x4_f32 issues 40 cycles after its producer, an independent one after 32
+        // (MI355X_MICROARCH.md): the MFMAs are therefore emitted round-robin over >= 2 independent accumulators -- the
+        // wave's WKT tiles, or, with a single tile, the even / odd fragments of the head dimension (summed afterwards).
+        constexpr int US = (WKT == 1 && NV >= 2) ? 2 : 1;
+        f32x4 sacc[WKT][US];
+        float kv[WKT][NV][VW];
+#pragma unroll
+        for (int w = 0; w < WKT; ++w) {
+            const float* kp = ks + ((kh * WKT + w) * 16 + j) * KSTR + VW * g;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                if constexpr (VW == 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(kp + 16 * u);
+                    kv[w][u][0] = t[0]; kv[w][u][1] = t[1]; kv[w][u][2] = t[2]; kv[w][u][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) kv[w][u][e] = kp[e];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < US; ++c) sacc[w][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u0 = 0; u0 < NV; u0 += US)
+#pragma unroll
+            for (int e = 0; e < VW; ++e)
+#pragma unroll
+                for (int c = 0; c < US; ++c)
+#pragma unroll
+                    for (int w = 0; w < WKT; ++w)
+                        if (u0 + c < NV) sacc[w][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[w][u0 + c][e], qreg[u0 + c][e], sacc[w][c], 0, 0, 0);
 #pragma unroll
         for (int w = 0; w < WKT; ++w) {
             const int kt = kh * WKT + w;
-            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* kp = ks + (kt * 16 + j) * KSTR + VW * g;
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                float kv[VW];
-                if constexpr (VW == 4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(kp + 16 * u);
-                    kv[0] = t[0]; kv[1] = t[1]; kv[2] = t[2]; kv[3] = t[3];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VW; ++e) kv[e] = kp[e];
-                }
-#pragma unroll
-                for (int e = 0; e < VW; ++e) s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[e], qreg[u][e], s4, 0, 0, 0);
-            }
+            f32x4 s4 = sacc[w][0];
+            if constexpr (US == 2) s4 += sacc[w][1];
             if constexpr (!FULL) {
                 // keys past the end of the segment, or masked out by the caller (unet.py:452-456), score -inf.  Branch-free:
                 // the mask bytes are fetched with a clamped index and folded into a select (the short-circuit form
@@ -314,9 +359,9 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool oob = key0 + r >= klen;
-                    unsigned mv = 1u;
-                    if (kmask) mv = kmask[oob ? 0 : key0 + r];
-                    s4[r] = (oob || mv == 0u) ? -INFINITY : s4[r];
+                    bool dead = oob;
+                    if constexpr (MODE == 2) dead = oob | (mv[w][r] == 0u);
+                    s4[r] = dead ? -INFINITY : s4[r];
                 }
             }
             st[w] = s4;
@@ -342,26 +387,44 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
                 ps += p;
             }
         lsum = lsum * alpha + ps;
+        // O^T += V^T P^T : A = V^T rows (d index) x keys, read as 4 consecutive keys per lane.  Independent accumulators
+        // round-robin again: the NOB output blocks, or (one block: d <= 16) the even / odd key tiles of the wave.
+        constexpr int OS = (NOB == 1 && WKT >= 2) ? 2 : 1;
+        f32x4 pacc[NOB][OS];
 #pragma unroll
-        for (int o = 0; o < NOB; ++o) oacc[o] *= alpha;
-        // O^T += V^T P^T : A = V^T rows (d index) x keys, read as 4 consecutive keys per lane
+        for (int o = 0; o < NOB; ++o) {
+            pacc[o][0] = oacc[o] * alpha;
+            if constexpr (OS == 2) pacc[o][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-        for (int w = 0; w < WKT; ++w) {
-            const int kt = kh * WKT + w;
+        for (int w0 = 0; w0 < WKT; w0 += OS) {
+            f32x4 v[OS][NOB];
 #pragma unroll
-            for (int o = 0; o < NOB; ++o) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(vt + (16 * o + j) * VSTR + kt * 16 + 4 * g);
+            for (int c = 0; c < OS; ++c)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) oacc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[s], st[w][s], oacc[o], 0, 0, 0);
-            }
+                for (int o = 0; o < NOB; ++o)
+                    v[c][o] = *reinterpret_cast<const f32x4*>(vt + (16 * o + j) * VSTR + (kh * WKT + w0 + c) * 16 + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < OS; ++c)
+#pragma unroll
+                    for (int o = 0; o < NOB; ++o)
+                        pacc[o][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c][o][s], st[w0 + c][s], pacc[o][c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int o = 0; o < NOB; ++o) {
+            oacc[o] = pacc[o][0];
+            if constexpr (OS == 2) oacc[o] += pacc[o][1];
         }
     };
     for (int kb = 0; kb < klen; kb += KB) {
         const bool more = kb + KB < klen;
         if (more) gload(kb + KB);                       // in flight under this block's math
-        if (kb + KB <= klen && !kmask) block(kb, std::true_type{});
-        else block(kb, std::false_type{});
-        if (more) lstore(buf ^ 1);
+        if (kmask) block(kb, std::integral_constant<int, 2>{});
+        else if (kb + KB <= klen) block(kb, std::integral_constant<int, 0>{});
+        else block(kb, std::integral_constant<int, 1>{});
+        if (more) lstore(buf ^ 1, kb + KB);
         __syncthreads();
         buf ^= 1;
     }
@@ -421,7 +484,19 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     else
         for (int i = 0; i < a.nseg; ++i) blocks64 += (a.seg_len[i] + 63) / 64;
     const bool wide = (blocks64 * a.H * a.B >= 256 && (!a.seg_uniform || a.seg_uniform >= 64)) || d >= 128;
-    const int qw = wide ? 4 : 1;
+    // 32-query workgroups (2 query tiles x 4 key parts) where 64-query ones give at most one workgroup per CU AND the
+    // segments differ in length (the plane attention of a [xy | yt | xt] clip: the xy workgroups walk twice the keys):
+    // 512 half-size workgroups, two per CU, let the dispatcher even that out (measured 19.2 -> 16.3 us at L = 2048, d = 16;
+    // with ONE segment the same change costs 2 us: twice the K/V staging for nothing).  MTV_ATT_QW=2|4 forces either.
+    static int wide_qw = -1;
+    if (wide_qw < 0) {
+        wide_qw = 0;
+        if (const char* e = getenv("MTV_ATT_QW")) wide_qw = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 0);
+    }
+    bool uneven = false;
+    for (int i = 1; i < a.nseg && !a.seg_uniform; ++i) uneven |= a.seg_len[i] != a.seg_len[0];
+    const bool half = wide && (d == 16 || d == 32) && (wide_qw == 2 || (wide_qw == 0 && uneven && blocks64 * a.H * a.B <= 256));
+    const int qw = wide ? (half ? 2 : 4) : 1;
     a.blk_prefix[0] = 0;
     if (a.seg_uniform) {
         a.nseg = 1;
@@ -430,14 +505,22 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     } else {
         for (int i = 0; i < a.nseg; ++i) a.blk_prefix[i + 1] = a.blk_prefix[i] + (a.seg_len[i] + 16 * qw - 1) / (16 * qw);
     }
-    dim3 grid((unsigned)(a.blk_prefix[a.nseg] * a.H * a.B));
+    const int nblk = a.blk_prefix[a.nseg];
+    for (int i = a.nseg + 1; i < 4; ++i) a.blk_prefix[i] = nblk;       // the kernel's branch-free decode reads [1], [2] and [3]
+    if (!a.seg_uniform) a.bps = 1;
+    if ((long)nblk * a.H * a.B >= (1l << 22)) return hipErrorInvalidValue;   // FDiv's exact range
+    a.inv_H = 1.0f / (float)a.H;
+    a.inv_nblk = 1.0f / (float)nblk;
+    a.inv_bps = 1.0f / (float)a.bps;
+    dim3 grid((unsigned)(nblk * a.H * a.B));
     static int wide_ksp = -1;                       // tuning aid: MTV_ATT_KSP=2|4 (key parts of the 4-tile shape)
     if (wide_ksp < 0) {
         wide_ksp = 2;   // 4 (1024-thread workgroups) measured equal in time; 2 keeps workgroups at 512 threads
         if (const char* e = getenv("MTV_ATT_KSP")) wide_ksp = atoi(e) == 4 ? 4 : 2;
     }
 #define MTV_ATT(D, KS1, KSW)                                                                         \
-    if (wide && KSW == 4 && wide_ksp == 4) hipLaunchKernelGGL((k_attention<D, 4, KSW>), grid, dim3(256 * KSW), 0, s, a); \
+    if (half) hipLaunchKernelGGL((k_attention<(D == 16 || D == 32 ? D : 16), 2, 4>), grid, dim3(512), 0, s, a); \
+    else if (wide && KSW == 4 && wide_ksp == 4) hipLaunchKernelGGL((k_attention<D, 4, KSW>), grid, dim3(256 * KSW), 0, s, a); \
     else if (wide) hipLaunchKernelGGL((k_attention<D, 4, 2>), grid, dim3(512), 0, s, a);             \
     else hipLaunchKernelGGL((k_attention<D, 1, KS1>), grid, dim3(64 * KS1), 0, s, a);
     switch (d) {

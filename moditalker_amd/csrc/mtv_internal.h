@@ -214,6 +214,7 @@ struct AttnArgs {
     // seg_uniform > 0 the token axis is cut into L / seg_uniform segments of that length and seg_start/len are unused
     int seg_uniform;
     int bps;                 // query blocks per uniform segment (set by launch_attention)
+    float inv_H, inv_nblk, inv_bps;   // reciprocals for the kernel's block decode (set by launch_attention)
     // cross-attention (CrossAttention, unet.py:429-467): `qkv` then holds the queries only ([B][L][C], head-major) and
     // kv the keys/values [B][Lkv][2C] (k | v of a head adjacent); one segment of all L queries
     const float* kv;
