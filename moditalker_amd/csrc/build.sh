@@ -13,7 +13,9 @@ wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC kernels.o conv.o plan.o ae.o xattn.o -o libmtv_hip.so
 echo "built $(pwd)/libmtv_hip.so"
 if [ -n "$MTV_BUILD_STAMP" ]; then   # diagnostic twin with in-kernel phase timestamps (tools/stamps.py)
-    $HIPCC $FLAGS -DMTV_ABLATE=64 -c conv.hip -o conv_stamp.o
-    $HIPCC --offload-arch=gfx950 -shared -fPIC kernels.o conv_stamp.o plan.o ae.o xattn.o -o libmtv_hip_stamp.so
+    $HIPCC $FLAGS -DMTV_ABLATE=64 -c conv.hip -o conv_stamp.o &
+    $HIPCC $FLAGS -DMTV_ATT_STAMP -c kernels.hip -o kernels_stamp.o &
+    wait
+    $HIPCC --offload-arch=gfx950 -shared -fPIC kernels_stamp.o conv_stamp.o plan.o ae.o xattn.o -o libmtv_hip_stamp.so
     echo "built $(pwd)/libmtv_hip_stamp.so"
 fi

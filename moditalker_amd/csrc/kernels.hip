@@ -173,9 +173,22 @@ __device__ __forceinline__ float lane_swap_max32(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+#ifdef MTV_ATT_STAMP   // phase timestamps of thread 0 of four sampled workgroups (first two, middle, last) -> a.dbg (tools/stamps.py)
+#define ATT_STAMP(k) do { if (threadIdx.x == 0 && a.dbg) { const int sb_ = blockIdx.x < 2 ? (int)blockIdx.x : (blockIdx.x == gridDim.x / 2 ? 2 : (blockIdx.x == gridDim.x - 1 ? 3 : -1)); \
+                          if (sb_ >= 0) a.dbg[sb_ * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define ATT_PUT(k, v) do { if (threadIdx.x == 0 && a.dbg) { const int sb_ = blockIdx.x < 2 ? (int)blockIdx.x : (blockIdx.x == gridDim.x / 2 ? 2 : (blockIdx.x == gridDim.x - 1 ? 3 : -1)); \
+                          if (sb_ >= 0) a.dbg[sb_ * 16 + (k)] = (v); } } while (0)
+#define ATT_ACC(x) do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); (x) += t1_ - att_t0; att_t0 = t1_; } while (0)
+#else
+#define ATT_STAMP(k) do { } while (0)
+#define ATT_PUT(k, v) do { } while (0)
+#define ATT_ACC(x) do { } while (0)
+#endif
+
 template <int D, int QW, int KSP>
 __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     touch_kernargs<(int)sizeof(AttnArgs)>();
+    ATT_STAMP(0);
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr int VW = D >= 16 ? 4 : D / 4;        // floats per q/k fragment
     constexpr int NV = D >= 16 ? D / 16 : 1;       // fragments per row
@@ -286,6 +299,7 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         }
     };
 
+    ATT_STAMP(1);
     gload(0);
     float qreg[NV][VW];
 #pragma unroll
@@ -294,7 +308,11 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         for (int e = 0; e < VW; ++e) qreg[u][e] = qok ? qraw[u][e] * scale * LOG2E : 0.f;   // scores in log2 units
     lstore(0, 0);
     __syncthreads();
+    ATT_STAMP(2);
     int buf = 0;
+    [[maybe_unused]] unsigned long long att_tb = 0, att_tw = 0, att_ts = 0, att_t0 = 0;
+    ATT_ACC(att_tb);
+    att_tb = 0;
     // One key block.  FULL (every key of the block exists -- all blocks but possibly the last) is a separate
     // instantiation: no per-element masking, no all-masked guard.  Scores are in the log2 domain (log2 e is
     // folded into q), so p = exp2(s - m) is one subtract + one v_exp_f32 per element; the cross-lane maxima
@@ -424,10 +442,17 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         if (kmask) block(kb, std::integral_constant<int, 2>{});
         else if (kb + KB <= klen) block(kb, std::integral_constant<int, 0>{});
         else block(kb, std::integral_constant<int, 1>{});
+        ATT_ACC(att_tb);
         if (more) lstore(buf ^ 1, kb + KB);
+        ATT_ACC(att_tw);
         __syncthreads();
+        ATT_ACC(att_ts);
         buf ^= 1;
     }
+    ATT_STAMP(3);
+    ATT_PUT(8, att_tb);
+    ATT_PUT(9, att_tw);
+    ATT_PUT(10, att_ts);
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
     if constexpr (KSP > 1) {
@@ -458,6 +483,7 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
             m = mt;
         }
     }
+    ATT_STAMP(4);
     const float inv = 1.0f / lsum;
     if (q0 + j < len) {
         float* op = a.out + ((size_t)b * a.L + start + q0 + j) * a.C + (size_t)h * D;
@@ -470,6 +496,7 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
                 if (4 * g + r < D) op[4 * g + r] = oacc[0][r] * inv;
         }
     }
+    ATT_STAMP(5);
 }
 
 hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {

@@ -220,6 +220,7 @@ struct AttnArgs {
     const float* kv;
     int Lkv;
     const unsigned char* kmask;   // [B][Lkv] or nullptr: 0 = key masked out
+    unsigned long long* dbg;      // diagnostic build (-DMTV_ATT_STAMP): phase timestamps of four sampled workgroups, else unused
 };
 
 struct LinearArgs {

@@ -507,6 +507,11 @@ struct Builder {
         for (int i = 0; i < t.nseg; ++i) aflops += 4.0 * B * H * (double)t.seg_len[i] * t.seg_len[i] * d;
         char tag[64];
         snprintf(tag, sizeof tag, "[L%d d%d %s]", L.L, d, whole ? "1d" : "2d");
+        static const bool att_stamps = getenv("MTV_STAMPS") != nullptr;       // diagnostic build only (mtv_debug_stamps)
+        if (att_stamps) {
+            t.dbg = reinterpret_cast<unsigned long long*>(c->buf("dbg.attn." + nm + "." + std::to_string(mode) + "." + std::to_string(B), 128));
+            plan->attn_dbg.emplace_back("attn:" + nm + tag, t.dbg);
+        }
         push("attn:" + nm + tag, [t](hipStream_t s) { return launch_attention(t, s); }, aflops, 4.0 * B * L.L * 4.0 * C);
 
         Tens out;
@@ -1317,6 +1322,7 @@ int mtv_debug_stamps(mtv_ctx* c, int batch, const char* path, void* stream) {
         if ((rc = sampler_setup(c, batch, nullptr, &one, 1, s)) != MTV_OK) return rc;
         for (auto& op : p->convs)
             if (op->a.dbg) HIPCHK(hipMemsetAsync(op->a.dbg, 0, 512, s));
+        for (auto& ad : p->attn_dbg) HIPCHK(hipMemsetAsync(ad.second, 0, 512, s));
         if ((rc = run_ops(c, p, s)) != MTV_OK) return rc;
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -1328,6 +1334,16 @@ int mtv_debug_stamps(mtv_ctx* c, int batch, const char* path, void* stream) {
         unsigned long long h[64];
         HIPCHK(hipMemcpy(h, op->a.dbg, sizeof h, hipMemcpyDeviceToHost));
         fprintf(f, "%s", p->ops[op->op_index].name.c_str());
+        for (int i = 0; i < 64; ++i) fprintf(f, " %llu", h[i]);
+        fprintf(f, "\n");
+    }
+    // attention launches (kernels.hip built with -DMTV_ATT_STAMP): 0=entry 1=decoded 2=first tile in LDS 3=key loop done
+    // 4=key parts merged 5=output stored; 8/9/10 = ticks summed over the key blocks: block math / LDS store of the next
+    // tile (incl. the wait for its loads) / barrier
+    for (auto& ad : p->attn_dbg) {
+        unsigned long long h[64];
+        HIPCHK(hipMemcpy(h, ad.second, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(f, "%s", ad.first.c_str());
         for (int i = 0; i < 64; ++i) fprintf(f, " %llu", h[i]);
         fprintf(f, "\n");
     }

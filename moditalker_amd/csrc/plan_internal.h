@@ -99,6 +99,7 @@ struct Plan {
     int B = 0;
     int mode = MODE_FORWARD;
     std::vector<std::shared_ptr<ConvOp>> convs;
+    std::vector<std::pair<std::string, unsigned long long*>> attn_dbg;   // (diagnostic build: stamp buffers of the attention launches)
     bool tuned = false;
     std::vector<Op> ops;           // UNet forward
     hipGraphExec_t g_forward = nullptr;

@@ -34,6 +34,7 @@ order = [7, 0, 8, 9, 10, 1, 2, 3, 4, 5, 6]
 # (s_memtime counters of different XCDs are not synchronised: only deltas INSIDE one workgroup mean anything)
 print("# us per phase, of the sampled workgroup whose own entry->exit span is longest: " + " | ".join(names) + " || span")
 tot = [0.0] * 11
+attn = []
 for line in open(args.raw):
     if line.startswith("#"):
         continue
@@ -42,6 +43,9 @@ for line in open(args.raw):
     name = " ".join(parts[:k])
     v = [int(x) for x in parts[k:]]
     blocks = [v[i * 16:(i + 1) * 16] for i in range(4)]
+    if name.startswith("attn:"):
+        attn.append((name, blocks))
+        continue
     blocks = [b for b in blocks if b[7] > 0]
     if not blocks:
         continue
@@ -60,3 +64,20 @@ for line in open(args.raw):
     tot[10] += span
     print(f"{name:52s} " + " ".join(f"{x:6.2f}" for x in ph) + f" || {span:6.2f}")
 print(f"{'# SUM':52s} " + " ".join(f"{x:6.1f}" for x in tot[:10]) + f" || {tot[10]:6.1f}")
+
+# attention launches (kernels.hip -DMTV_ATT_STAMP): wave 0 of the sampled workgroup with the longest span
+if attn:
+    print("# attention, us: args+decode | first tile (loads -> LDS -> barrier) | key loop = block math + next-tile store (incl. load wait) "
+          "+ barrier | merge | store || span")
+    at = [0.0] * 9
+    for name, blocks in attn:
+        blocks = [b for b in blocks if b[0] > 0 and b[5] > 0]
+        if not blocks:
+            continue
+        b = max(blocks, key=lambda x: x[5] - x[0])
+        us = lambda x: x / args.mhz
+        row = [us(b[1] - b[0]), us(b[2] - b[1]), us(b[3] - b[2]), us(b[8]), us(b[9]), us(b[10]), us(b[4] - b[3]), us(b[5] - b[4]), us(b[5] - b[0])]
+        for i, x in enumerate(row):
+            at[i] += x
+        print(f"{name:40s} {row[0]:6.2f} {row[1]:6.2f} {row[2]:6.2f} = {row[3]:6.2f} + {row[4]:6.2f} + {row[5]:6.2f} | {row[6]:6.2f} {row[7]:6.2f} || {row[8]:6.2f}")
+    print(f"{'# SUM attention':40s} {at[0]:6.1f} {at[1]:6.1f} {at[2]:6.1f} = {at[3]:6.1f} + {at[4]:6.1f} + {at[5]:6.1f} | {at[6]:6.1f} {at[7]:6.1f} || {at[8]:6.1f}")

@@ -1,0 +1,155 @@
+// Do a wave's softmax VALU instructions overlap the f32 MFMAs of the OTHER wave on its SIMD (or its own)?
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 mfma_valu.hip -o mfma_valu
+// Models one key block of k_attention<16,4,2> per loop iteration and wave: 16 QK^T MFMAs (4 tiles x 4 steps), a softmax
+// pass over the 16 scores of every lane (max, 2 lane swaps, 17 exp2, sums), 16 PV MFMAs that take the probabilities as
+// B operand.  256 workgroups x 8 waves (2 waves per SIMD, like the level-0 attentions of the B = 1 step).
+//   mode 0: MFMAs only          mode 1: VALU only
+//   mode 2: phased (QK, softmax, PV), workgroup barrier every iteration (what the kernel does)
+//   mode 3: phased, no barrier
+//   mode 4: phased, barrier, the odd waves of a SIMD (wave >= 4) start half an iteration late (one extra softmax first)
+//   mode 5: two half-blocks software-pipelined in the wave (QK of half B || softmax of half A, PV of A || softmax of B)
+// Prints cycles per iteration of wave 0 (s_memtime) and the wall-clock rate.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float swapmax16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float swapmax32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int NT>
+__device__ __forceinline__ void qk(f32x4 (&st)[NT], const float (&kq)[4][4], const float (&q)[4]) {
+#pragma unroll
+    for (int w = 0; w < NT; ++w) st[w] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int w = 0; w < NT; ++w) st[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[w][e], q[e], st[w], 0, 0, 0);
+}
+template <int NT>
+__device__ __forceinline__ float soft(f32x4 (&st)[NT], float& m, float& l) {
+    float mx = st[0][0];
+#pragma unroll
+    for (int w = 0; w < NT; ++w)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[w][r]);
+    mx = swapmax16(mx);
+    mx = swapmax32(mx);
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT; ++w)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(st[w][r] - mn);
+            st[w][r] = p;
+            ps += p;
+        }
+    l = l * alpha + ps;
+    return alpha;
+}
+template <int NT>
+__device__ __forceinline__ void pv(f32x4& o, const f32x4 (&st)[NT], const float (&v)[4][4], float alpha) {
+    o *= alpha;
+#pragma unroll
+    for (int w = 0; w < NT; ++w)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_16x16x4f32(v[w][s], st[w][s], o, 0, 0, 0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float kq[4][4], v[4][4], q[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            kq[w][e] = 0.01f * (float)((lane * 7 + w * 3 + e) % 13) - 0.05f;
+            v[w][e] = 0.02f * (float)((lane * 5 + w + e * 3) % 11) - 0.1f;
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[e] = 0.03f * (float)((lane + e) % 9) - 0.1f;
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -1e30f, l = 0.f;
+    f32x4 st[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) st[w] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+    if (MODE == 4 && wave >= 4) {   // skew: the second wave of every SIMD does one softmax before entering the loop
+        const float al = soft<4>(st, m, l);
+        o *= al;
+    }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        q[0] += 1e-6f;   // (keeps the iterations distinct)
+        if constexpr (MODE == 0) {
+            qk<4>(st, kq, q);
+            pv<4>(o, st, v, 1.0f);
+        } else if constexpr (MODE == 1) {
+            const float al = soft<4>(st, m, l);
+            o *= al;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) st[w] = st[w] * 0.5f + o;
+        } else if constexpr (MODE == 2 || MODE == 3 || MODE == 4) {
+            qk<4>(st, kq, q);
+            const float al = soft<4>(st, m, l);
+            pv<4>(o, st, v, al);
+            if constexpr (MODE != 3) __syncthreads();
+        } else {
+            f32x4 sa[2], sb[2];
+            const float ka[4][4] = {{kq[0][0], kq[0][1], kq[0][2], kq[0][3]}, {kq[1][0], kq[1][1], kq[1][2], kq[1][3]}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            const float kb[4][4] = {{kq[2][0], kq[2][1], kq[2][2], kq[2][3]}, {kq[3][0], kq[3][1], kq[3][2], kq[3][3]}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            const float va[4][4] = {{v[0][0], v[0][1], v[0][2], v[0][3]}, {v[1][0], v[1][1], v[1][2], v[1][3]}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            const float vb[4][4] = {{v[2][0], v[2][1], v[2][2], v[2][3]}, {v[3][0], v[3][1], v[3][2], v[3][3]}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            qk<2>(sa, ka, q);
+            qk<2>(sb, kb, q);
+            const float a1 = soft<2>(sa, m, l);
+            pv<2>(o, sa, va, a1);
+            const float a2 = soft<2>(sb, m, l);
+            pv<2>(o, sb, vb, a2);
+            __syncthreads();
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = o[0] + o[1] + o[2] + o[3] + l + m + st[0][0];
+}
+
+template <int MODE>
+static void run(const char* name, float* out, unsigned long long* cyc, int waves_per_wg) {
+    const int iters = 4000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(64 * waves_per_wg), 0, 0, out, cyc, 100);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(64 * waves_per_wg), 0, 0, out, cyc, iters);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h; CK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost));
+    printf("%-58s waves/WG %d: %7.1f ticks/iter (s_memtime), %6.3f us/iter wall\n", name, waves_per_wg, (double)h / iters, ms * 1e3 / iters);
+}
+
+int main() {
+    float* out; unsigned long long* cyc;
+    CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 64));
+    for (int wv : {4, 8}) {
+        run<0>("0 MFMA only (32 per iteration)", out, cyc, wv);
+        run<1>("1 VALU only (softmax of 16 scores per lane)", out, cyc, wv);
+        run<2>("2 phased QK / softmax / PV, barrier", out, cyc, wv);
+        run<3>("3 phased, no barrier", out, cyc, wv);
+        run<4>("4 phased, barrier, second wave of a SIMD skewed", out, cyc, wv);
+        run<5>("5 two half blocks pipelined in the wave, barrier", out, cyc, wv);
+    }
+    return 0;
+}
