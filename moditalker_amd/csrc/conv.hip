@@ -978,14 +978,20 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
         for (int nb = 0; nb < WN; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf) {
         const float* Ab = As + buf * BM * ASTR + (wm * 16 * WM + i) * ASTR + 4 * q;
-        const float* Bb = Bs + buf * 16 * BSTR + (4 * q) * BSTR + wn * 16 * WN + WN * i;
+        // a lane's WN output columns: WN <= 4: consecutive (wn 16 WN + WN i + nb); WN == 8: two quads 64 columns apart
+        // (wn 128 + 64 (nb >> 2) + 4 i + (nb & 3)) so that both are conflict-free 16-byte reads of 16 consecutive quads
+        const float* Bb = Bs + buf * 16 * BSTR + (4 * q) * BSTR + wn * 16 * WN + (WN == 8 ? 4 : WN) * i;
         f32x4 af[WM];
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(Ab + 16 * mt * ASTR);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float bv[WN];
-            if constexpr (WN == 4) {
+            if constexpr (WN == 8) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(Bb + s * BSTR), u = *reinterpret_cast<const f32x4*>(Bb + s * BSTR + 64);
+                bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+                bv[4] = u[0]; bv[5] = u[1]; bv[6] = u[2]; bv[7] = u[3];
+            } else if constexpr (WN == 4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(Bb + s * BSTR);
                 bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
             } else {
@@ -1013,12 +1019,15 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
     // ---- epilogue straight from the accumulators: lane (i, q) of wave (wm, wn) holds, for row 4q + r of row block mt, the
     // WN consecutive output channels n0 + 16 WN wn + WN i ..
     const bool fast = a.nstat > 0;
-    const int colw = n0 + wn * 16 * WN + WN * i;
     constexpr int QPR = BN / 4;
-    if (colw < a.N) {
-        float bias[WN];
+    constexpr int NG = WN == 8 ? 2 : 1, GW = WN / NG;          // column groups of a lane / their width (see compute)
 #pragma unroll
-        for (int nb = 0; nb < WN; ++nb) {
+    for (int cg = 0; cg < NG; ++cg) {
+        const int colw = n0 + wn * 16 * WN + (WN == 8 ? 64 * cg + 4 * i : WN * i);
+        if (colw >= a.N) continue;
+        float bias[GW];
+#pragma unroll
+        for (int nb = 0; nb < GW; ++nb) {
             bias[nb] = a.bias[colw + nb];
             if (a.bias2) bias[nb] += a.bias2[colw + nb];
             if (a.bias_b) bias[nb] += a.bias_b[(size_t)b * a.bias_b_stride + colw + nb];
@@ -1030,27 +1039,27 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
                 const int row = wm * 16 * WM + 16 * mt + 4 * q + r;
                 const int tok = tok0 + row;
                 if (tok >= a.Lout) continue;
-                float o[WN];
+                float o[GW];
 #pragma unroll
-                for (int nb = 0; nb < WN; ++nb) o[nb] = acc[mt][nb][r] + bias[nb];
+                for (int nb = 0; nb < GW; ++nb) o[nb] = acc[mt][cg * GW + nb][r] + bias[nb];
                 if (a.res) {
                     const int rs = idx[a.ntaps * BM + row];
                     const float* rp = a.res + ((size_t)b * a.Lskip + rs) * a.N + colw;
 #pragma unroll
-                    for (int nb = 0; nb < WN; ++nb) o[nb] += rp[nb];
+                    for (int nb = 0; nb < GW; ++nb) o[nb] += rp[nb];
                 }
                 float* op = a.out + ((size_t)b * a.Lout + tok) * a.N + colw;
-                if constexpr (WN == 4) *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
+                if constexpr (GW == 4) *reinterpret_cast<f32x4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
                 else *reinterpret_cast<f32x2*>(op) = f32x2{o[0], o[1]};
                 if (fast) {
                     const int sgq = seg_of(a.seg_out, tok);
                     double sq = 0.0, ssq = 0.0;
 #pragma unroll
-                    for (int nb = 0; nb < WN; ++nb) {
+                    for (int nb = 0; nb < GW; ++nb) {
                         sq += (double)o[nb];
                         ssq += (double)o[nb] * o[nb];
                     }
-                    const int cq = (colw - n0) >> 2;               // (WN == 2: two lanes share a quad slot)
+                    const int cq = (colw - n0) >> 2;               // (GW == 2: two lanes share a quad slot)
                     atomicAdd(&qs[(sgq * QPR + cq) * 2], sq);
                     atomicAdd(&qs[(sgq * QPR + cq) * 2 + 1], ssq);
                 }
@@ -1283,7 +1292,8 @@ hipError_t conv_init_attrs() {
     if ((e = conv_attr_nw<1, 2>()) != hipSuccess) return e;
     if ((e = conv_attr_nw<1, 1>()) != hipSuccess) return e;
     const void* tiled[] = {reinterpret_cast<const void*>(&k_conv_lds<4, 4>), reinterpret_cast<const void*>(&k_conv_lds<2, 4>),
-                           reinterpret_cast<const void*>(&k_conv_lds<4, 2>), reinterpret_cast<const void*>(&k_conv_lds<2, 2>)};
+                           reinterpret_cast<const void*>(&k_conv_lds<4, 2>), reinterpret_cast<const void*>(&k_conv_lds<2, 2>),
+                           reinterpret_cast<const void*>(&k_conv_lds<2, 8>), reinterpret_cast<const void*>(&k_conv_lds<4, 8>)};
     for (const void* f : tiled)
         if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
     return hipSuccess;
@@ -1310,6 +1320,8 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
         if (t.MT == 2 && t.NT == 4) return launch_conv_lds_t<2, 4>(a, s);
         if (t.MT == 4 && t.NT == 2) return launch_conv_lds_t<4, 2>(a, s);
         if (t.MT == 2 && t.NT == 2) return launch_conv_lds_t<2, 2>(a, s);
+        if (t.MT == 2 && t.NT == 8) return launch_conv_lds_t<2, 8>(a, s);
+        if (t.MT == 4 && t.NT == 8) return launch_conv_lds_t<4, 8>(a, s);
         return hipErrorInvalidValue;
     }
     if (t.MT == 4 && t.NT == 4) e = launch_conv_nw<4, 4>(a, t.NW, s);

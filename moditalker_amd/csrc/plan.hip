@@ -661,7 +661,7 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
         g_force_wm = 0;
         if (const char* e = getenv("MTV_FORCE_LDS")) {
             int x = 0, y = 0;
-            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 2 || x == 4) && (y == 2 || y == 4)) { g_force_wm = x; g_force_wn = y; }
+            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 2 || x == 4) && (y == 2 || y == 4 || y == 8)) { g_force_wm = x; g_force_wn = y; }
         }
     }
     if (g_force_wm > 0 && conv_lds_eligible(a)) *t = ConvTile{g_force_wm, g_force_wn, 32, 1, 0};
@@ -772,7 +772,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
         if (it != c->tune_cache.end()) {             // an entry read from MTV_TUNE_CACHE is only trusted if it is launchable
             const ConvTile& t = it->second;
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
-            const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
+            const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
             const bool shape_ok = tiled_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
@@ -831,9 +831,12 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             }
             // the LDS-tiled kernel for large token counts (>= 2048 rows in all: fewer would leave most CUs idle)
             if ((long)a.B * a.Lout >= 2048 && conv_lds_eligible(a)) {
-                static const int tl[][2] = {{4, 4}, {2, 4}, {4, 2}, {2, 2}};
+                // (x 8: 256-column tiles.  Chosen for the autoencoder's widest GEMMs (N = 1536 / 3072 at 16384 tokens); never
+                // for a UNet conv, although the GroupNorm / FiLM / SiLU transform is repeated per column tile)
+                static const int tl[][2] = {{4, 4}, {2, 4}, {4, 2}, {2, 2}, {2, 8}, {4, 8}};
                 for (auto& mn : tl) {
                     const ConvTile t{mn[0], mn[1], 32, 1, 0};
+                    if (mn[1] == 8 && a.N < 256) continue;
                     if ((long)a.B * ((a.Lout + 32 * t.MT - 1) / (32 * t.MT)) * ((a.N + 32 * t.NT - 1) / (32 * t.NT)) < 128) continue;
                     if (conv_smem_bytes(a, t) > 120 * 1024) continue;
                     float samp[16];
@@ -1396,7 +1399,7 @@ int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up)
 
 int mtv_debug_force_lds(int wm, int wn) {
     if (wm == 0) { g_force_wm = 0; return MTV_OK; }
-    if (!((wm == 2 || wm == 4) && (wn == 2 || wn == 4))) return fail(MTV_ERR_INVALID, "wave tile must be 2 or 4 by 2 or 4");
+    if (!((wm == 2 || wm == 4) && (wn == 2 || wn == 4 || wn == 8))) return fail(MTV_ERR_INVALID, "wave tile must be 2 or 4 by 2, 4 or 8");
     g_force_wm = wm;
     g_force_wn = wn;
     return MTV_OK;

@@ -299,7 +299,7 @@ def test_module_copies_and_data_writes():
     assert torch.equal(net(x, cond, ic, t), a)   # (same context, same plan: bit-equal)
 
 
-@pytest.mark.parametrize("wm,wn", [(2, 4), (4, 2), (4, 4)])
+@pytest.mark.parametrize("wm,wn", [(2, 4), (4, 2), (4, 4), (2, 8), (4, 8)])
 def test_lds_tiled_conv_kernel_vs_reference_golden(wm, wn):
     """k_conv_lds (the large-token-count kernel: operands staged in LDS, 2x2 waves per workgroup) forced onto every
     eligible conv of the base UNet: eps vs the reference golden, and a ragged 2-clip geometry vs the oracle."""
