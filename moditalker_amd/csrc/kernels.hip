@@ -185,7 +185,20 @@ __device__ __forceinline__ float lane_swap_max32(float x) {
 #define ATT_ACC(x) do { } while (0)
 #endif
 
-template <int D, int QW, int KSP>
+// LDS of one k_attention workgroup (floats): K stages | V^T stages | key-part merge records.  KBX = 2 doubles the key block
+// (half the barriers / tile hand-overs per segment; above the 64 KB static limit, hence dynamic LDS throughout).
+template <int D, int QW, int KSP, int KBX>
+struct AttShape {
+    static constexpr int KSTR = D + (D >= 16 ? 4 : 0);
+    static constexpr int KB = (D >= 128 ? 16 : (D >= 64 ? 32 : (D >= 32 ? 64 : 128))) * KBX;
+    static constexpr int VSTR = KB + 4, VROWS = D < 16 ? 16 : D;
+    static constexpr int NOB = D >= 16 ? D / 16 : 1, XW = NOB * 4 + 2;
+    static constexpr int KS_FLOATS = 2 * KB * KSTR, VT_FLOATS = 2 * VROWS * VSTR;
+    static constexpr int XO_FLOATS = KSP > 1 ? (KSP - 1) * QW * XW * 64 : 4;
+    static constexpr size_t BYTES = (size_t)(KS_FLOATS + VT_FLOATS + XO_FLOATS) * 4;
+};
+
+template <int D, int QW, int KSP, int KBX = 1>
 __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     touch_kernargs<(int)sizeof(AttnArgs)>();
     ATT_STAMP(0);
@@ -197,7 +210,8 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     // hit 16 distinct bank quads -- (KSTR/4 * j + g) mod 16 must be a permutation of j: KSTR/4 odd.  (D = 16 ran unpadded
     // through round 2's first half: stride 16 floats = a 4-way conflict on every K fragment of the level-0 attentions.)
     constexpr int KSTR = D + (D >= 16 ? 4 : 0);
-    constexpr int KB = D >= 128 ? 16 : (D >= 64 ? 32 : (D >= 32 ? 64 : 128));   // keys per block (LDS budget)
+    constexpr int KB = AttShape<D, QW, KSP, KBX>::KB;   // keys per block (LDS budget)
+    static_assert(KSTR == AttShape<D, QW, KSP, KBX>::KSTR, "LDS layout");
     constexpr int NKT = KB / 16;                   // 16-key tiles per block
     constexpr int WKT = NKT / KSP;                 // ... of which each wave takes WKT
     static_assert(WKT >= 1, "key split wider than the key block");
@@ -206,10 +220,13 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     constexpr int QPR = D / 4;                     // float4 quads per K/V row
     constexpr int NTH = 64 * QW * KSP;
     constexpr int NLD = (KB * QPR + NTH - 1) / NTH;   // float4 loads per thread per tile
-    __shared__ __attribute__((aligned(16))) float Ks[2][KB * KSTR];
-    __shared__ __attribute__((aligned(16))) float Vt[2][VROWS * VSTR];
+    extern __shared__ __attribute__((aligned(16))) float att_smem[];
+    typedef float ks_row_t[KB * KSTR];
+    typedef float vt_row_t[VROWS * VSTR];
+    ks_row_t* Ks = reinterpret_cast<ks_row_t*>(att_smem);                                                       // [2][KB * KSTR]
+    vt_row_t* Vt = reinterpret_cast<vt_row_t*>(att_smem + AttShape<D, QW, KSP, KBX>::KS_FLOATS);                // [2][VROWS * VSTR]
+    float* Xo = att_smem + AttShape<D, QW, KSP, KBX>::KS_FLOATS + AttShape<D, QW, KSP, KBX>::VT_FLOATS;
     constexpr int XW = NOB * 4 + 2;                // merge record per lane: m, l, O^T registers
-    __shared__ float Xo[KSP > 1 ? (KSP - 1) * QW * XW * 64 : 4];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -499,6 +516,26 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     ATT_STAMP(5);
 }
 
+template <int D, int QW, int KSP, int KBX>
+static hipError_t att_launch(const AttnArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((k_attention<D, QW, KSP, KBX>), grid, dim3(64 * QW * KSP), (AttShape<D, QW, KSP, KBX>::BYTES), s, a);
+    return hipGetLastError();
+}
+template <int D, int QW, int KSP, int KBX>
+static hipError_t att_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<D, QW, KSP, KBX>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+}
+// Dynamic LDS above 64 KB must be opted into once per kernel (the KBX = 2 shapes); done at context creation, never under capture.
+hipError_t attn_init_attrs() {
+    hipError_t e;
+    if ((e = att_attr<16, 4, 2, 2>()) != hipSuccess) return e;
+    if ((e = att_attr<16, 1, 4, 2>()) != hipSuccess) return e;
+    if ((e = att_attr<32, 4, 2, 2>()) != hipSuccess) return e;
+    if ((e = att_attr<32, 1, 4, 2>()) != hipSuccess) return e;
+    if ((e = att_attr<64, 4, 2, 2>()) != hipSuccess) return e;
+    return att_attr<64, 1, 4, 2>();
+}
+
 hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     const int d = a.C / a.H;
@@ -540,28 +577,41 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     a.inv_nblk = 1.0f / (float)nblk;
     a.inv_bps = 1.0f / (float)a.bps;
     dim3 grid((unsigned)(nblk * a.H * a.B));
-    static int wide_ksp = -1;                       // tuning aid: MTV_ATT_KSP=2|4 (key parts of the 4-tile shape)
-    if (wide_ksp < 0) {
-        wide_ksp = 2;   // 4 (1024-thread workgroups) measured equal in time; 2 keeps workgroups at 512 threads
-        if (const char* e = getenv("MTV_ATT_KSP")) wide_ksp = atoi(e) == 4 ? 4 : 2;
+    // Double key blocks (KBX = 2: 256 / 128 / 64 keys at d = 16 / 32 / 64, 80-88 KB of LDS) where the launch has at most one
+    // workgroup per CU anyway and a segment spans more than one base block: half the per-block barriers and tile
+    // hand-overs, a prefetch distance longer than the load latency, and -- d = 64, short segments -- four key parts
+    // (waves) per workgroup instead of two.  With more workgroups than CUs the smaller footprint (3-4 resident
+    // workgroups per CU) hides latency better and stays.  MTV_ATT_KBX=1 switches it off.
+    static int kbx_env = -1;
+    if (kbx_env < 0) {
+        kbx_env = 2;
+        if (const char* e = getenv("MTV_ATT_KBX")) kbx_env = atoi(e) == 1 ? 1 : 2;
     }
-#define MTV_ATT(D, KS1, KSW)                                                                         \
-    if (half) hipLaunchKernelGGL((k_attention<(D == 16 || D == 32 ? D : 16), 2, 4>), grid, dim3(512), 0, s, a); \
-    else if (wide && KSW == 4 && wide_ksp == 4) hipLaunchKernelGGL((k_attention<D, 4, KSW>), grid, dim3(256 * KSW), 0, s, a); \
-    else if (wide) hipLaunchKernelGGL((k_attention<D, 4, 2>), grid, dim3(512), 0, s, a);             \
-    else hipLaunchKernelGGL((k_attention<D, 1, KS1>), grid, dim3(64 * KS1), 0, s, a);
+    int maxk = a.kv ? a.Lkv : a.seg_uniform;
+    if (!a.kv && !a.seg_uniform)
+        for (int i = 0; i < a.nseg; ++i) maxk = a.seg_len[i] > maxk ? a.seg_len[i] : maxk;
+    const int base_kb = d >= 64 ? 32 : (d >= 32 ? 64 : 128);
+    const bool big = kbx_env == 2 && !half && (d == 16 || d == 32 || d == 64) && (long)nblk * a.H * a.B <= 256 && maxk > base_kb;
+#define MTV_ATT_GO(D, QW, KSP, KBX) return att_launch<D, QW, KSP, KBX>(a, grid, s)
     switch (d) {
-        case 4: MTV_ATT(4, 4, 4); break;
-        case 8: MTV_ATT(8, 4, 4); break;
-        case 16: MTV_ATT(16, 4, 4); break;
-        case 32: MTV_ATT(32, 4, 4); break;
-        case 48: MTV_ATT(48, 4, 4); break;      // the autoencoder's quant stacks (autoencoder_vit.py:140-142: dim_head = 384/8)
-        case 64: MTV_ATT(64, 2, 2); break;
-        case 128: hipLaunchKernelGGL((k_attention<128, 4, 1>), grid, dim3(256), 0, s, a); break;
+        case 4: if (wide) MTV_ATT_GO(4, 4, 2, 1); else MTV_ATT_GO(4, 1, 4, 1);
+        case 8: if (wide) MTV_ATT_GO(8, 4, 2, 1); else MTV_ATT_GO(8, 1, 4, 1);
+        case 16:
+            if (half) MTV_ATT_GO(16, 2, 4, 1);
+            if (wide) { if (big) MTV_ATT_GO(16, 4, 2, 2); else MTV_ATT_GO(16, 4, 2, 1); }
+            if (big) MTV_ATT_GO(16, 1, 4, 2); else MTV_ATT_GO(16, 1, 4, 1);
+        case 32:
+            if (half) MTV_ATT_GO(32, 2, 4, 1);
+            if (wide) { if (big) MTV_ATT_GO(32, 4, 2, 2); else MTV_ATT_GO(32, 4, 2, 1); }
+            if (big) MTV_ATT_GO(32, 1, 4, 2); else MTV_ATT_GO(32, 1, 4, 1);
+        case 48: if (wide) MTV_ATT_GO(48, 4, 2, 1); else MTV_ATT_GO(48, 1, 4, 1);   // the autoencoder's quant stacks (autoencoder_vit.py:140-142: dim_head = 384/8)
+        case 64:
+            if (wide) { if (big) MTV_ATT_GO(64, 4, 2, 2); else MTV_ATT_GO(64, 4, 2, 1); }
+            if (big) MTV_ATT_GO(64, 1, 4, 2); else MTV_ATT_GO(64, 1, 2, 1);
+        case 128: MTV_ATT_GO(128, 4, 1, 1);
         default: return hipErrorInvalidValue;
     }
-#undef MTV_ATT
-    return hipGetLastError();
+#undef MTV_ATT_GO
 }
 
 // =====================================================================================

@@ -258,6 +258,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv(const ConvArgs& a, ConvTile t, hipStream_t s);
 hipError_t conv_init_attrs();
+hipError_t attn_init_attrs();
 hipError_t launch_gn_stats(const StatsArgs& a, hipStream_t s);
 hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);

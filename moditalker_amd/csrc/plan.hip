@@ -904,6 +904,7 @@ int ctx_init_common(mtv_ctx* c) {
     HIPCHK(hipGetDevice(&c->device));
     if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     HIPCHK(conv_init_attrs());     // dynamic LDS above 64 KB must be opted into once per kernel (never under capture)
+    HIPCHK(attn_init_attrs());
     return MTV_OK;
 }
 
