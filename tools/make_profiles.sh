@@ -37,9 +37,13 @@ timeout 300 python tools/ae_profile.py > $O/r${NN}_ae_decode_per_launch.txt 2>/d
 timeout 300 python tools/ae_profile.py --extract > $O/r${NN}_ae_extract_per_launch.txt 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktae -o kt -- python tools/ae_profile.py > /dev/null 2>&1
 cp "$(find $O/ktae -name '*kernel_stats.csv' | head -1)" $O/r${NN}_ae_decode_rocprofv3_kernel_stats.csv
-# 8. the in-kernel phase anatomy of every conv of a step (diagnostic build with s_memtime stamps)
-MTV_LIB=$PWD/moditalker_amd/csrc/libmtv_hip_stamp.so MTV_STAMPS=1 timeout 300 python tools/stamps.py > $O/r${NN}_conv_phase_stamps.txt 2>/dev/null
-# 9. the launch-chain microbenchmark
+# 8. the in-kernel phase anatomy of every conv and every attention launch of a step (diagnostic build with s_memtime
+#    stamps: MTV_BUILD_STAMP=1 bash moditalker_amd/csrc/build.sh)
+MTV_LIB=$PWD/moditalker_amd/csrc/libmtv_hip_stamp.so MTV_STAMPS=1 timeout 300 python tools/stamps.py > $O/stamps_all.txt 2>/dev/null
+sed -n '/^# attention/,$p' $O/stamps_all.txt > $O/r${NN}_attention_phase_stamps.txt
+sed '/^# attention/,$d' $O/stamps_all.txt > $O/r${NN}_conv_phase_stamps.txt
+# 9. micro-benchmarks: the launch chain, f32 MFMA vs VALU on one SIMD
 timeout 120 tools/ubench/chain > $O/r${NN}_launch_chain_ubench.txt 2>&1
+timeout 120 tools/ubench/mfma_valu > $O/r${NN}_mfma_valu_ubench.txt 2>&1
 rm -rf $O/kt $O/ktae $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 tail -25 $O/r${NN}_step_summary.txt
