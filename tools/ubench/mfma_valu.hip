@@ -8,6 +8,8 @@
 //   mode 3: phased, no barrier
 //   mode 4: phased, barrier, the odd waves of a SIMD (wave >= 4) start half an iteration late (one extra softmax first)
 //   mode 5: two half-blocks software-pipelined in the wave (QK of half B || softmax of half A, PV of A || softmax of B)
+//   modes 8-10: the conv K loop's mix (one 16-channel chunk of a k_conv<1,4,*> wave per iteration): SiLU of 4 elements +
+//   16 f32 MFMAs, against the same products as a 3-term bf16 split (6 products per pair, v_mfma_f32_16x16x16_bf16)
 // Prints cycles per iteration of wave 0 (s_memtime) and the wall-clock rate.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -64,6 +66,80 @@ __device__ __forceinline__ void pv(f32x4& o, const f32x4 (&st)[NT], const float 
     for (int w = 0; w < NT; ++w)
 #pragma unroll
         for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_16x16x4f32(v[w][s], st[w][s], o, 0, 0, 0);
+}
+
+// ---- the conv K loop's mix: one 16-channel chunk of a k_conv<1,4,*> wave per iteration = the SiLU transform of 4 A elements
+// (fma, exp2, add, rcp, mul each) + 16 f32 MFMAs (mode 8) -- or the same products as a 3-term bf16 split: A split in
+// registers (two subtract/convert rounds), W pre-split, 6 x 4 = 24 v_mfma_f32_16x16x16_bf16 (modes 9: MFMAs only, 10: all)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * v)); }
+__device__ __forceinline__ short bf16_rn(float x) {   // round-to-nearest-even bf16 of a finite float, as bits
+    const unsigned u = __float_as_uint(x);
+    return (short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_up(short h) { return __uint_as_float(((unsigned)(unsigned short)h) << 16); }
+
+template <int MODE>
+__global__ __launch_bounds__(512) void kc(float* out, unsigned long long* cyc, int iters) {
+    const int lane = threadIdx.x & 63;
+    float x[4], w[4][4];
+    s16x4 wb[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        x[e] = 0.01f * (float)((lane * 7 + e) % 13) - 0.05f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) w[e][nb] = 0.02f * (float)((lane * 5 + nb + e * 3) % 11) - 0.1f;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) wb[t][nb] = s16x4{(short)(lane + t), (short)(nb * 3 + 1), (short)(t * 5 + 2), (short)(lane ^ nb)};
+    f32x4 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[e] += 1e-6f;
+            y[e] = (MODE == 9) ? x[e] : silu_fast(fmaf(x[e], 1.01f, 0.02f));
+        }
+        if constexpr (MODE == 8) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[s2], w[s2][nb], acc[nb], 0, 0, 0);
+        } else {
+            s16x4 ab[3];
+            if constexpr (MODE == 10) {   // 3-term split of the lane's 4 A values
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const short h0 = bf16_rn(y[e]);
+                    const float r1 = y[e] - bf16_up(h0);
+                    const short h1 = bf16_rn(r1);
+                    const float r2 = r1 - bf16_up(h1);
+                    ab[0][e] = h0; ab[1][e] = h1; ab[2][e] = bf16_rn(r2);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) ab[t] = s16x4{(short)__float_as_uint(y[0]), (short)t, (short)(t + 1), (short)lane};
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[0], wb[0][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[0], wb[1][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[1], wb[0][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[0], wb[2][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[1], wb[1][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[2], wb[0][nb], acc[nb], 0, 0, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
 }
 
 template <int MODE>
@@ -140,6 +216,21 @@ static void run(const char* name, float* out, unsigned long long* cyc, int waves
     printf("%-58s waves/WG %d: %7.1f ticks/iter (s_memtime), %6.3f us/iter wall\n", name, waves_per_wg, (double)h / iters, ms * 1e3 / iters);
 }
 
+template <int MODE>
+static void runc(const char* name, float* out, unsigned long long* cyc, int waves_per_wg) {
+    const int iters = 8000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kc<MODE>, dim3(256), dim3(64 * waves_per_wg), 0, 0, out, cyc, 100);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kc<MODE>, dim3(256), dim3(64 * waves_per_wg), 0, 0, out, cyc, iters);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h; CK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost));
+    printf("%-58s waves/WG %d: %7.1f ticks/iter (s_memtime), %6.3f us/iter wall\n", name, waves_per_wg, (double)h / iters, ms * 1e3 / iters);
+}
+
 int main() {
     float* out; unsigned long long* cyc;
     CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 64));
@@ -150,6 +241,9 @@ int main() {
         run<3>("3 phased, no barrier", out, cyc, wv);
         run<4>("4 phased, barrier, second wave of a SIMD skewed", out, cyc, wv);
         run<5>("5 two half blocks pipelined in the wave, barrier", out, cyc, wv);
+        runc<8>("8 conv chunk: SiLU of 4 elements + 16 f32 MFMAs", out, cyc, wv);
+        runc<9>("9 conv chunk: 24 bf16 MFMAs (3-term split, 6 products)", out, cyc, wv);
+        runc<10>("10 conv chunk: SiLU + A split + 24 bf16 MFMAs", out, cyc, wv);
     }
     return 0;
 }
