@@ -10,6 +10,7 @@
 //   mode 5: two half-blocks software-pipelined in the wave (QK of half B || softmax of half A, PV of A || softmax of B)
 //   modes 8-10: the conv K loop's mix (one 16-channel chunk of a k_conv<1,4,*> wave per iteration): SiLU of 4 elements +
 //   16 f32 MFMAs, against the same products as a 3-term bf16 split (6 products per pair, v_mfma_f32_16x16x16_bf16)
+//   modes 11-13: a 32-channel step with gfx950's v_mfma_f32_16x16x32_bf16 and the split through v_cvt_pk_bf16_f32
 // Prints cycles per iteration of wave 0 (s_memtime) and the wall-clock rate.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -142,6 +143,73 @@ __global__ __launch_bounds__(512) void kc(float* out, unsigned long long* cyc, i
     out[(size_t)blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
 }
 
+// ---- the same for a 32-channel step: 8 SiLU + 32 f32 MFMAs (mode 11) against 8 SiLU + the 3-term split through the
+// hardware conversion (v_cvt_pk_bf16_f32) + 24 v_mfma_f32_16x16x32_bf16 (mode 12); mode 13: those 24 MFMAs alone
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int MODE>
+__global__ __launch_bounds__(512) void kd(float* out, unsigned long long* cyc, int iters) {
+    const int lane = threadIdx.x & 63;
+    float x[8], w[8][4];
+    bf16x8 wb[3][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        x[e] = 0.01f * (float)((lane * 7 + e) % 13) - 0.05f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) w[e][nb] = 0.02f * (float)((lane * 5 + nb + e * 3) % 11) - 0.1f;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wb[t][nb][e] = (__bf16)(0.01f * (float)((lane + t * 3 + nb * 5 + e) % 17) - 0.08f);
+    f32x4 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x[e] += 1e-6f;
+            y[e] = (MODE == 13) ? x[e] : silu_fast(fmaf(x[e], 1.01f, 0.02f));
+        }
+        if constexpr (MODE == 11) {
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[s2], w[s2][nb], acc[nb], 0, 0, 0);
+        } else {
+            bf16x8 ab[3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (MODE == 12) {
+                    const __bf16 h0 = (__bf16)y[e];
+                    const float r1 = y[e] - (float)h0;
+                    const __bf16 h1 = (__bf16)r1;
+                    const float r2 = r1 - (float)h1;
+                    ab[0][e] = h0; ab[1][e] = h1; ab[2][e] = (__bf16)r2;
+                } else {
+                    ab[0][e] = (__bf16)y[e]; ab[1][e] = ab[0][e]; ab[2][e] = ab[0][e];
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[0], wb[0][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[0], wb[1][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[1], wb[0][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[0], wb[2][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[1], wb[1][nb], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[2], wb[0][nb], acc[nb], 0, 0, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -231,6 +299,21 @@ static void runc(const char* name, float* out, unsigned long long* cyc, int wave
     printf("%-58s waves/WG %d: %7.1f ticks/iter (s_memtime), %6.3f us/iter wall\n", name, waves_per_wg, (double)h / iters, ms * 1e3 / iters);
 }
 
+template <int MODE>
+static void rund(const char* name, float* out, unsigned long long* cyc, int waves_per_wg) {
+    const int iters = 8000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kd<MODE>, dim3(256), dim3(64 * waves_per_wg), 0, 0, out, cyc, 100);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kd<MODE>, dim3(256), dim3(64 * waves_per_wg), 0, 0, out, cyc, iters);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h; CK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost));
+    printf("%-58s waves/WG %d: %7.1f ticks/iter (s_memtime), %6.3f us/iter wall\n", name, waves_per_wg, (double)h / iters, ms * 1e3 / iters);
+}
+
 int main() {
     float* out; unsigned long long* cyc;
     CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 64));
@@ -244,6 +327,9 @@ int main() {
         runc<8>("8 conv chunk: SiLU of 4 elements + 16 f32 MFMAs", out, cyc, wv);
         runc<9>("9 conv chunk: 24 bf16 MFMAs (3-term split, 6 products)", out, cyc, wv);
         runc<10>("10 conv chunk: SiLU + A split + 24 bf16 MFMAs", out, cyc, wv);
+        rund<11>("11 32 channels: 8 SiLU + 32 f32 MFMAs", out, cyc, wv);
+        rund<13>("13 32 channels: 24 bf16 16x16x32 MFMAs alone", out, cyc, wv);
+        rund<12>("12 32 channels: 8 SiLU + cvt split + 24 bf16 16x16x32", out, cyc, wv);
     }
     return 0;
 }
