@@ -547,7 +547,9 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     if (a.seg_uniform) blocks64 = (long)nuni * ((a.seg_uniform + 63) / 64);
     else
         for (int i = 0; i < a.nseg; ++i) blocks64 += (a.seg_len[i] + 63) / 64;
-    const bool wide = (blocks64 * a.H * a.B >= 256 && (!a.seg_uniform || a.seg_uniform >= 64)) || d >= 128;
+    // (>= 128 workgroups of 8 waves already beat 4x as many 16-query workgroups, each of which stages every key of its
+    // segment: L = 1536, d = 64 at R = 64 ran 768 two-wave workgroups for 125 us)
+    const bool wide = (blocks64 * a.H * a.B >= 128 && (!a.seg_uniform || a.seg_uniform >= 64)) || d >= 128;
     // 32-query workgroups (2 query tiles x 4 key parts) where 64-query ones give at most one workgroup per CU AND the
     // segments differ in length (the plane attention of a [xy | yt | xt] clip: the xy workgroups walk twice the keys):
     // 512 half-size workgroups, two per CU, let the dispatcher even that out (measured 19.2 -> 16.3 us at L = 2048, d = 16;
