@@ -540,7 +540,8 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     const int d = a.C / a.H;
     // Workgroup shape: QW query tiles (16 queries each) x KSP key parts of every key block.
-    //   long segments : 4 x 2 (8 waves, 2 per SIMD: one wave's softmax VALU overlaps the other's MFMAs)
+    //   long segments : 4 x 2 (8 waves, 2 per SIMD.  Not for overlap -- f32 MFMA time and softmax VALU time ADD on a SIMD,
+    //                   tools/ubench/mfma_valu -- but to share one K/V staging among 64 queries)
     //   short segments: 1 x 4 -- there are too few query tiles to fill 256 CUs, so the keys are split instead
     long blocks64 = 0;
     const int nuni = a.seg_uniform ? a.L / a.seg_uniform : 0;
