@@ -72,6 +72,11 @@ class CrossAttention(nn.Module):
             with torch.cuda.device(device):
                 for k, v in self.state_dict().items():
                     t = v.detach().to(device=device, dtype=torch.float32).contiguous()
+                    if t.data_ptr() != v.data_ptr():
+                        # a converted / copied temporary is produced on torch's CURRENT stream, while mtv_load_weight copies and
+                        # repacks on the NULL stream: finish producing it first (it stays referenced until the call returns,
+                        # and the call returns only after its own copy + repack have run)
+                        torch.cuda.current_stream(device).synchronize()
                     shp = (C.c_int64 * t.dim())(*t.shape)
                     _lib.check(lib.mtv_load_weight(self._ctx, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), shp), f"mtv_load_weight({k})")
             self._fingerprint = fp

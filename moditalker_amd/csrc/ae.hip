@@ -555,10 +555,9 @@ int get_ae_plan(mtv_ctx* c, const mtv_ae_config& f, int B, int mode, Plan** out)
 
 }  // namespace
 
-// the AE configuration of a context (kept beside the generic mtv_ctx, keyed by context)
-static std::map<mtv_ctx*, mtv_ae_config>& ae_cfgs() {
-    static std::map<mtv_ctx*, mtv_ae_config> m;
-    return m;
+// the AE configuration of a context: owned by the context itself (mtv_ctx::ext), nullptr for any other kind of context
+static const mtv_ae_config* ae_cfg_of(const mtv_ctx* c) {
+    return c && c->kind == CTX_AE ? static_cast<const mtv_ae_config*>(c->ext.get()) : nullptr;
 }
 
 extern "C" {
@@ -598,25 +597,26 @@ int mtv_ae_create(const mtv_ae_config* cfg, mtv_ctx** out) {
     }
     if (!c->buf("ae.rot_time", (size_t)D.T * 2 * D.d) || !c->buf("ae.rot_space", (size_t)D.n * 2 * D.d))
         return fail(MTV_ERR_HIP, "rotary table allocation failed");
-    ae_cfgs()[c.get()] = f;
+    c->kind = CTX_AE;
+    c->ext = std::make_shared<mtv_ae_config>(f);
     // build both batch-1 plans now: registers every weight slot
     Plan* p = nullptr;
-    if ((rc = get_ae_plan(c.get(), f, 1, MODE_AE_DECODE, &p)) != MTV_OK) { ae_cfgs().erase(c.get()); return rc; }
-    if ((rc = get_ae_plan(c.get(), f, 1, MODE_AE_EXTRACT, &p)) != MTV_OK) { ae_cfgs().erase(c.get()); return rc; }
+    if ((rc = get_ae_plan(c.get(), f, 1, MODE_AE_DECODE, &p)) != MTV_OK) return rc;
+    if ((rc = get_ae_plan(c.get(), f, 1, MODE_AE_EXTRACT, &p)) != MTV_OK) return rc;
     *out = c.release();
     return MTV_OK;
 }
 
 int mtv_ae_destroy(mtv_ctx* c) {
-    if (c) ae_cfgs().erase(c);
+    if (c && c->kind != CTX_AE) return fail(MTV_ERR_INVALID, "not an autoencoder context");
     delete c;
     return MTV_OK;
 }
 
 int mtv_ae_set_rotary(mtv_ctx* c, const float* time_tab, const float* space_tab) {
-    auto it = ae_cfgs().find(c);
-    if (it == ae_cfgs().end() || !time_tab || !space_tab) return fail(MTV_ERR_INVALID, "not an autoencoder context / null table");
-    const AeDims D = dims_of(it->second);
+    const mtv_ae_config* cf = ae_cfg_of(c);
+    if (!cf || !time_tab || !space_tab) return fail(MTV_ERR_INVALID, "not an autoencoder context / null table");
+    const AeDims D = dims_of(*cf);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(c->bufs["ae.rot_time"], time_tab, (size_t)D.T * 2 * D.d * 4, hipMemcpyDefault));
     HIPCHK(hipMemcpy(c->bufs["ae.rot_space"], space_tab, (size_t)D.n * 2 * D.d * 4, hipMemcpyDefault));
@@ -625,14 +625,14 @@ int mtv_ae_set_rotary(mtv_ctx* c, const float* time_tab, const float* space_tab)
 
 static int ae_run(mtv_ctx* c, int mode, const float* in, size_t in_floats, const char* in_buf, float* outp, size_t out_floats,
                   const char* out_buf, int batch, hipStream_t s) {
-    auto it = ae_cfgs().find(c);
-    if (it == ae_cfgs().end()) return fail(MTV_ERR_INVALID, "not an autoencoder context");
+    const mtv_ae_config* cf = ae_cfg_of(c);
+    if (!cf) return fail(MTV_ERR_INVALID, "not an autoencoder context");
     int rc = check_ready(c, batch);
     if (rc != MTV_OK) return rc;
     if (!in || !outp) return fail(MTV_ERR_INVALID, "null tensor pointer");
     HIPCHK(hipSetDevice(c->device));
     Plan* p = nullptr;
-    if ((rc = get_ae_plan(c, it->second, batch, mode, &p)) != MTV_OK) return rc;
+    if ((rc = get_ae_plan(c, *cf, batch, mode, &p)) != MTV_OK) return rc;
     if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
     HIPCHK(hipMemcpyAsync(c->bufs[in_buf], in, in_floats * 4, hipMemcpyDeviceToDevice, s));
     if (c->eager) {
@@ -646,30 +646,30 @@ static int ae_run(mtv_ctx* c, int mode, const float* in, size_t in_floats, const
 }
 
 int mtv_ae_decode(mtv_ctx* c, const float* latents, float* frames_out, int batch, void* stream) {
-    auto it = ae_cfgs().find(c);
-    if (it == ae_cfgs().end()) return fail(MTV_ERR_INVALID, "not an autoencoder context");
-    const AeDims D = dims_of(it->second);
+    const mtv_ae_config* cf = ae_cfg_of(c);
+    if (!cf) return fail(MTV_ERR_INVALID, "not an autoencoder context");
+    const AeDims D = dims_of(*cf);
     return ae_run(c, MODE_AE_DECODE, latents, (size_t)batch * D.E * D.L, "ae.lat_in", frames_out,
                   (size_t)batch * D.T * 3 * D.res * D.res, "ae.frames_out", batch, (hipStream_t)stream);
 }
 
 int mtv_ae_extract(mtv_ctx* c, const float* video, float* latents_out, int batch, void* stream) {
-    auto it = ae_cfgs().find(c);
-    if (it == ae_cfgs().end()) return fail(MTV_ERR_INVALID, "not an autoencoder context");
-    const AeDims D = dims_of(it->second);
+    const mtv_ae_config* cf = ae_cfg_of(c);
+    if (!cf) return fail(MTV_ERR_INVALID, "not an autoencoder context");
+    const AeDims D = dims_of(*cf);
     return ae_run(c, MODE_AE_EXTRACT, video, (size_t)batch * 3 * D.T * D.res * D.res, "ae.video_in", latents_out,
                   (size_t)batch * D.E * D.L, "ae.lat_out", batch, (hipStream_t)stream);
 }
 
 int mtv_ae_profile(mtv_ctx* c, int batch, int extract, int iters, mtv_op_time* out, int cap, int* n_out, void* stream) {
-    auto it = ae_cfgs().find(c);
-    if (it == ae_cfgs().end() || !n_out || iters < 1) return fail(MTV_ERR_INVALID, "not an autoencoder context / bad argument");
+    const mtv_ae_config* cf = ae_cfg_of(c);
+    if (!cf || !n_out || iters < 1) return fail(MTV_ERR_INVALID, "not an autoencoder context / bad argument");
     int rc = check_ready(c, batch);
     if (rc != MTV_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
     Plan* p = nullptr;
-    if ((rc = get_ae_plan(c, it->second, batch, extract ? MODE_AE_EXTRACT : MODE_AE_DECODE, &p)) != MTV_OK) return rc;
+    if ((rc = get_ae_plan(c, *cf, batch, extract ? MODE_AE_EXTRACT : MODE_AE_DECODE, &p)) != MTV_OK) return rc;
     if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
     const int n = (int)p->ops.size();
     *n_out = n;

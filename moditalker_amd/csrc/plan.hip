@@ -672,23 +672,27 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
 // one per 16x16 output tile (the finest tiling), zeroed once here -- every launch leaves them at zero again.
 int finish_split_k(mtv_ctx* c, Plan* plan) {
     const int B = plan->B;
-    const std::string tag = std::to_string(B) + (plan->mode >= MODE_AE_DECODE ? ".ae" : "");
+    // UNet plans of one batch size (forward, step 0 / 1) have identical convs and share slab + counters; the two
+    // autoencoder plans differ, so each gets its own (keyed by mode): mtv_ctx::buf() refuses a second, larger request
+    const std::string tag = std::to_string(B) + (plan->mode >= MODE_AE_DECODE ? ".ae.m" + std::to_string(plan->mode) : "");
     size_t need = 0;
     for (auto& op : plan->convs) {
         const size_t one = (size_t)B * op->a.Lout * op->a.N;
         size_t ks = 16;
         while (ks > 1 && ks * one * 4 > ((size_t)64 << 20)) ks /= 2;
         if ((size_t)op->t.KS > ks) ks = op->t.KS;
+        if (ks < 2) continue;                       // never split: needs no slab (the autoencoder's 16384-token GEMMs)
         need = ks * one > need ? ks * one : need;
     }
     float* slab = c->buf("slab.B" + tag, need);
-    if (!slab) return fail(MTV_ERR_HIP, "slab allocation failed");
-    if (c->slab_floats[B] < need) c->slab_floats[B] = need;
+    if (!slab) return fail(MTV_ERR_HIP, "slab allocation failed: " + std::string(mtv_last_error()));
+    // what the tuner may use = what is really allocated for THIS plan (autotune validates K slices against it)
+    plan->slab_floats = c->buf_floats["slab.B" + tag];
     for (auto& op : plan->convs) op->a.slab = slab;
     size_t nt = 0;
     for (auto& op : plan->convs) nt += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
-    int* tk = (int*)c->buf("tickets.B" + tag + ".m" + std::to_string(plan->mode >= MODE_AE_DECODE ? plan->mode : 0), nt);
-    if (!tk) return fail(MTV_ERR_HIP, "ticket allocation failed");
+    int* tk = (int*)c->buf("tickets.B" + tag, nt);
+    if (!tk) return fail(MTV_ERR_HIP, "ticket allocation failed: " + std::string(mtv_last_error()));
     for (auto& op : plan->convs) {
         op->a.tickets = tk;
         tk += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
@@ -756,7 +760,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     HIPCHK(hipEventCreate(&ev.e1));
     hipEvent_t e0 = ev.e0, e1 = ev.e1;
     static const int nsamp = []() { const char* e = getenv("MTV_TUNE_SAMPLES"); const int v = e ? atoi(e) : 5; return v < 1 ? 1 : (v > 15 ? 15 : v); }();
-    const size_t slab_cap = c->slab_floats[p->B];
+    const size_t slab_cap = p->slab_floats;
     if (!c->flush) {
         c->flush_bytes = (size_t)320 << 20;
         int rcm = c->dmalloc((void**)&c->flush, c->flush_bytes);

@@ -101,14 +101,20 @@ struct Plan {
     std::vector<std::shared_ptr<ConvOp>> convs;
     std::vector<std::pair<std::string, unsigned long long*>> attn_dbg;   // (diagnostic build: stamp buffers of the attention launches)
     bool tuned = false;
+    size_t slab_floats = 0;        // floats of the split-K slab this plan's convs share (finish_split_k)
     std::vector<Op> ops;           // UNet forward
     hipGraphExec_t g_forward = nullptr;
 };
 
 
+enum CtxKind { CTX_UNET = 0, CTX_AE = 1, CTX_XATTN = 2 };
+
 struct mtv_ctx {
     mtv_config cfg{};
     int device = 0;
+    int kind = CTX_UNET;                        // which C-ABI family owns this context
+    std::shared_ptr<void> ext;                  // CTX_AE: mtv_ae_config; CTX_XATTN: its weight / workspace record -- lives and dies
+                                                // with the context (no process-global side tables, nothing to lock)
     std::vector<Level> lv;
     std::vector<Stage> inputs, outputs;
     Stage middle;
@@ -119,6 +125,7 @@ struct mtv_ctx {
     std::vector<WSlot> slots;
     std::map<std::string, int> slot_index;
     std::map<std::string, float*> bufs;         // named activation / weight buffers
+    std::map<std::string, size_t> buf_floats;   // ... and the size each was allocated with
     std::map<std::string, std::pair<int, int>> taps;   // tap name -> (level, C) ; buffer = bufs["tap." + name]
     std::vector<void*> allocs;
     std::vector<int*> g3, gup3, gup1;           // gather tables per level
@@ -149,7 +156,6 @@ struct mtv_ctx {
     bool accounting = false;
     float* staging = nullptr;
     size_t staging_floats = 0;
-    std::map<int, size_t> slab_floats;                    // per batch size
     std::map<std::string, ConvTile> tune_cache;           // conv shape -> measured best tile
     void* flush = nullptr;                                // cache-flush scratch for cold auto-tune timing
     size_t flush_bytes = 0;
@@ -162,13 +168,23 @@ struct mtv_ctx {
         allocs.push_back(*p);
         return MTV_OK;
     }
+    // named buffer, allocated (zero-filled) on first use.  Asking again for MORE than the first request is an error
+    // (nullptr + mtv_last_error): captured graphs hold the pointer, so it can neither move nor be outgrown silently.
     float* buf(const std::string& name, size_t floats) {
         auto it = bufs.find(name);
-        if (it != bufs.end()) return it->second;
+        if (it != bufs.end()) {
+            auto sz = buf_floats.find(name);
+            if (sz != buf_floats.end() && floats > sz->second) {
+                fail(MTV_ERR_STATE, "buffer '" + name + "' requested with " + std::to_string(floats) + " floats but allocated with " + std::to_string(sz->second));
+                return nullptr;
+            }
+            return it->second;
+        }
         void* p = nullptr;
         if (dmalloc(&p, floats * sizeof(float)) != MTV_OK) return nullptr;
         (void)hipMemset(p, 0, floats * sizeof(float));
         bufs[name] = (float*)p;
+        buf_floats[name] = floats;
         return (float*)p;
     }
     float* act(const std::string& name, int lvl, int C) {   // [max_batch][L_lvl][C]

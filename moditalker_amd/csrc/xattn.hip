@@ -31,9 +31,8 @@ struct XCfg {
     float *Wq, *Wkv, *Wo, *bo, *zero, *q, *kv, *att;
     int ldq, ldkv, ldo;
 };
-std::map<mtv_ctx*, XCfg>& xcfgs() {
-    static std::map<mtv_ctx*, XCfg> m;
-    return m;
+const XCfg* xcfg_of(const mtv_ctx* c) {      // owned by the context (mtv_ctx::ext)
+    return c && c->kind == CTX_XATTN ? static_cast<const XCfg*>(c->ext.get()) : nullptr;
 }
 int pad64(int n) { return (n + 63) / 64 * 64; }
 
@@ -91,22 +90,23 @@ int mtv_xattn_create(const mtv_xattn_config* cfg, mtv_ctx** out) {
     c->slot("to_v.weight", {inner, f.context_dim}, ROLE_KV_HEADS, x.Wkv, x.ldkv)->aux = d * 2 + 1;
     c->slot("to_out.0.weight", {f.query_dim, inner}, ROLE_CONV, x.Wo, x.ldo);
     x.bo = c->wcopy("to_out.0.bias", {f.query_dim});
-    xcfgs()[c.get()] = x;
+    c->kind = CTX_XATTN;
+    c->ext = std::make_shared<XCfg>(x);
     *out = c.release();
     return MTV_OK;
 }
 
 int mtv_xattn_destroy(mtv_ctx* c) {
-    if (c) xcfgs().erase(c);
+    if (c && c->kind != CTX_XATTN) return fail(MTV_ERR_INVALID, "not a cross-attention context");
     delete c;
     return MTV_OK;
 }
 
 int mtv_xattn_forward(mtv_ctx* c, const float* x, const float* context, const unsigned char* mask, float* out, int batch,
                       int n_queries, int n_keys, void* stream) {
-    auto it = xcfgs().find(c);
-    if (it == xcfgs().end()) return fail(MTV_ERR_INVALID, "not a cross-attention context");
-    const XCfg& X = it->second;
+    const XCfg* xp = xcfg_of(c);
+    if (!xp) return fail(MTV_ERR_INVALID, "not a cross-attention context");
+    const XCfg& X = *xp;
     int rc = check_ready(c, batch);
     if (rc != MTV_OK) return rc;
     if (!x || !out) return fail(MTV_ERR_INVALID, "null tensor pointer");

@@ -29,11 +29,24 @@ from .unet import DiffusionWrapper, UNetModel
 
 
 def make_beta_schedule(schedule: str, n_timestep: int, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3) -> np.ndarray:
-    # ddpm.py:77-99.  The sampling path only ever builds the "linear" schedule (DDPM's default, never overridden by
-    # sample.py:239-245 or the shipped configs); the other names the reference accepts are not part of this path.
-    if schedule != "linear":
-        raise NotImplementedError(f"beta schedule '{schedule}': only 'linear' is reachable from the MToV sampling path")
-    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
+    """The four schedule names `DDPM(beta_schedule=...)` accepts in the reference (ddpm.py:78-99), as fp64 arrays.
+    The sampling path itself only ever builds "linear" (DDPM's default; sample.py:239-245 and the shipped configs never
+    override it); the others are host-only arithmetic kept for constructor parity."""
+    ramp = partial(torch.linspace, steps=n_timestep, dtype=torch.float64)
+    if schedule == "linear":            # linear in sqrt(beta)
+        betas = ramp(linear_start ** 0.5, linear_end ** 0.5).square()
+    elif schedule == "sqrt_linear":     # (the reference's name for: linear in beta)
+        betas = ramp(linear_start, linear_end)
+    elif schedule == "sqrt":
+        betas = ramp(linear_start, linear_end).sqrt()
+    elif schedule == "cosine":          # alpha_bar(t) = cos^2((t/T + s) / (1 + s) * pi/2), normalised to alpha_bar(0) = 1
+        grid = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep
+        abar = torch.cos((grid + cosine_s) / (1 + cosine_s) * (np.pi / 2)).square()
+        abar = abar / abar[0]
+        betas = (1 - abar[1:] / abar[:-1]).clamp(0, 0.999)
+    else:
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    return betas.numpy()
 
 
 def ddim_time_pairs(total_timesteps: int, sampling_timesteps: int) -> List[Tuple[int, int]]:

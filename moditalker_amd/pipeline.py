@@ -13,8 +13,10 @@ Restates, step for step,
 
 This is host logic (numpy / PIL for the image formats, torch for device tensors); every model call goes to the HIP library.
 `sample.py` itself is not importable (module-level argparse, hard-wired paths, cv2 / torchvision / omegaconf) and the disc
-rasteriser it uses, cv2.circle, is not installed here: `_disc_rows` restates OpenCV's filled-circle scan conversion
-(modules/imgproc/src/drawing.cpp, Circle(), OpenCV 4.x) and is NOT pinned against cv2 itself -- see DESIGN.md.
+rasteriser it uses, cv2.circle, is not installed here: `_disc_rows` produces the row spans of OpenCV's filled-circle scan
+conversion (modules/imgproc/src/drawing.cpp, Circle(), OpenCV 4.x).  It is checked bit for bit against golden bitmaps and
+against oracle/ref_circle.py, a statement-for-statement restatement of Circle() incl. its clipping path
+(tests/test_pipeline_host.py); cv2 itself never ran here, see DESIGN.md section 4.
 """
 from __future__ import annotations
 
@@ -51,6 +53,17 @@ def _disc_rows(radius: int) -> List[Tuple[int, int]]:
     return out
 
 
+def _draw_disc(img: np.ndarray, cx: int, cy: int, rows: Sequence[Tuple[int, int]], value: int = 255) -> None:
+    """One filled disc, clipped to the image ([H, W] or [H, W, C], in place): row cy + dy spans cx - hw .. cx + hw."""
+    h, w = img.shape[:2]
+    for dy, hw in rows:
+        yy = cy + dy
+        if 0 <= yy < h:
+            x0, x1 = max(cx - hw, 0), min(cx + hw, w - 1)
+            if x0 <= x1:
+                img[yy, x0:x1 + 1] = value
+
+
 def landmarks_to_images(lm: np.ndarray, WH: int = 256, flip: bool = False) -> np.ndarray:
     """dataloader_sample.py:153-179 `_change_np_img_size`: lm [T, 68, 2] (image-sized ints) or [T, 68, 3] (normalised
     3-D) -> uint8 [T, 256, 256, 3], white filled radius-3 discs on black; optional vertical flip."""
@@ -64,13 +77,7 @@ def landmarks_to_images(lm: np.ndarray, WH: int = 256, flip: bool = False) -> np
     rows = _disc_rows(3)
     for b in range(T):
         for x, y in lm2d[b]:
-            cx, cy = int(x / WH * 256.0), int(y / WH * 256.0)
-            for dy, hw in rows:
-                yy = cy + dy
-                if 0 <= yy < 256:
-                    x0, x1 = max(cx - hw, 0), min(cx + hw, 255)
-                    if x0 <= x1:
-                        img[b, yy, x0:x1 + 1] = 255
+            _draw_disc(img[b], int(x / WH * 256.0), int(y / WH * 256.0), rows)
     if flip:
         img = img[:, ::-1].copy()
     return img
@@ -180,8 +187,9 @@ class MToVSampler:
             os.makedirs(folder, exist_ok=True)
             for idx in range(u8.shape[0]):
                 Image.fromarray(u8[idx], "RGB").save(os.path.join(folder, f"{idx}.png"))
-            names = sorted(os.listdir(folder))                   # sample.py:347-348
-            u8 = np.stack([np.asarray(Image.open(os.path.join(folder, n)).convert("RGB")) for n in names], axis=0)
+            # read back exactly what was just written, in clip order.  (sample.py:347-348 lists and sorts the folder: stale
+            # PNGs of an earlier, larger batch would join the batch there, and "10.png" sorts before "2.png".)
+            u8 = np.stack([np.asarray(Image.open(os.path.join(folder, f"{idx}.png")).convert("RGB")) for idx in range(u8.shape[0])], axis=0)
         dev = next(self.ae.parameters()).device
         ref = reference_from_uint8(u8, frames=self.ae.s).to(dev)
         return self.ae.extract(ref)[:, :, 0:self.n_xy]
@@ -191,8 +199,8 @@ class MToVSampler:
                      out_dir: Optional[str] = None, noise_per_chunk: Optional[Sequence] = None, **sample_kw):
         """The per-identity loop (sample.py:305-432): chunks yield (x_ref, x, x_l, masked_x) in 0..255, [B,T,C,H,W].
         Chunks of one identity are sequential when chained (chunk k+1 needs chunk k's last frame): shard by identity.
-        Returns the list of uint8 frame arrays [B, T, H, W, 3]; writes frames/NNNN.png (first clip of the batch, as the
-        reference's single-column grid) when out_dir is given."""
+        Returns the list of uint8 frame arrays [B, T, H, W, 3]; when out_dir is given writes frames/NNNN.png with the B clips
+        of the batch side by side ([H, B*W, 3] per frame), the reference's grid_size=(k, 1) layout (sample.py:79-104)."""
         results = []
         image_cond = None
         for it, (x_ref, x, x_l, masked_x) in enumerate(chunks):
@@ -205,5 +213,5 @@ class MToVSampler:
             u8 = frames_to_uint8(fake)
             results.append(u8)
             if out_dir is not None:
-                save_frames(ldmk_srt, u8[0], os.path.join(out_dir, "frames"))
+                save_frames(ldmk_srt, np.concatenate(list(u8), axis=2), os.path.join(out_dir, "frames"))
         return results

@@ -251,6 +251,11 @@ class UNetModel(nn.Module):
             if k not in sd:
                 raise _lib.MtvError(f"library expects weight '{k}' which this module does not hold")
             t = sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
+            if t.data_ptr() != sd[k].data_ptr():
+                # a converted / copied temporary is produced on torch's CURRENT stream, while mtv_load_weight copies and
+                # repacks on the NULL stream: finish producing it first (it stays referenced until the call returns,
+                # and the call returns only after its own copy + repack have run)
+                torch.cuda.current_stream(device).synchronize()
             shp = (C.c_int64 * t.dim())(*t.shape)
             _lib.check(lib.mtv_load_weight(self._ctx, k.encode(), C.c_void_p(t.data_ptr()), t.dim(), shp), f"mtv_load_weight({k})")
         missing = lib.mtv_weights_missing(self._ctx)

@@ -48,6 +48,21 @@ def test_schedule_buffers_bit_equal_reference():
     assert len(pairs) == 25 and pairs[0][0] == 249 and pairs[-1] == (9, -1)
 
 
+def test_all_beta_schedules_bit_equal_reference():
+    """DDPM(beta_schedule=...) accepts the reference's four names (ddpm.py:78-99); every 50th beta of each schedule at
+    (1000, .0015, .0195) was captured from the reference's make_beta_schedule (tests/golden/make_golden_schedules.py)."""
+    from moditalker_amd.ddpm import make_beta_schedule
+    g = np.load(os.path.join(GOLDEN, "beta_schedules.npz"))
+    for name in ("linear", "cosine", "sqrt_linear", "sqrt"):
+        b = make_beta_schedule(name, 1000, 0.0015, 0.0195)
+        assert b.dtype == np.float64 and b.shape == (1000,)
+        assert np.array_equal(b[::50], g[name]), name
+    with pytest.raises(ValueError):
+        make_beta_schedule("quadratic", 1000)
+    dm = DDPM(torch.nn.Identity(), beta_schedule="cosine", sampling_timesteps=50)
+    assert float(dm.betas.max()) == np.float32(0.999) and dm.betas.dtype == torch.float32
+
+
 def test_ddim_step_table_matches_reference_arithmetic():
     from oracle import ref_ddpm
     buf = ref_ddpm.schedule_buffers()

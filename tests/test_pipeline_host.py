@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import GOLDEN
 from moditalker_amd import pipeline as P
 
 
@@ -120,3 +121,69 @@ def test_chunk_loop_ordering_and_chaining(tmp_path):
     ae2, dm2 = _StubAE(), _StubDM()
     P.MToVSampler(dm2, ae2).run_identity(chunks, use_last_as_reference=False)
     assert all(abs(float(c["image_cond"].mean()) - 1.0) < 1e-6 for c in dm2.calls) and all(c["noised_start"] is None for c in dm2.calls)
+
+
+def test_batched_identity_writes_the_reference_grid_and_ignores_stale_pngs(tmp_path):
+    """B = 2 clips per call: frames/NNNN.png holds both clips side by side ([H, 2W, 3], the reference's grid_size=(k, 1),
+    sample.py:79-104), and the chained image_cond is read back from exactly the two files just written -- a stale
+    `5.png` of an earlier, larger batch in the same folder does not join the batch."""
+    ae, dm = _StubAE(), _StubDM()
+    s = P.MToVSampler(dm, ae)
+    mk = lambda a, b: torch.cat([torch.full((1, 16, 3, 8, 8), float(a)), torch.full((1, 16, 3, 8, 8), float(b))], dim=0)
+    chunks = [(mk(255, 0), mk(10, 90), mk(20, 80), mk(30, 70)), (mk(255, 0), mk(40, 60), mk(50, 50), mk(60, 40))]
+    from PIL import Image
+    stale = tmp_path / "references" / "16"
+    os.makedirs(stale)
+    Image.fromarray(np.full((8, 8, 3), 77, np.uint8), "RGB").save(stale / "5.png")
+    out = s.run_identity(chunks, use_last_as_reference=True, out_dir=str(tmp_path))
+    assert out[0].shape == (2, 16, 8, 8, 3)
+    grid = np.asarray(Image.open(tmp_path / "frames" / "0000.png"))
+    assert grid.shape == (8, 16, 3)
+    assert np.array_equal(grid[:, :8], out[0][0, 0]) and np.array_equal(grid[:, 8:], out[0][1, 0])
+    assert dm.calls[1]["image_cond"].shape[0] == 2            # not 3: the stale file stayed out
+
+
+def _read_bitmaps(name):
+    out, cur, title = [], [], None
+    for line in open(os.path.join(GOLDEN, name)).read().splitlines():
+        if line.startswith("#"):
+            if title is not None:
+                out.append((title, np.array(cur, dtype=np.uint8)))
+            title, cur = line[2:], []
+        else:
+            cur.append([1 if ch == "X" else 0 for ch in line])
+    out.append((title, np.array(cur, dtype=np.uint8)))
+    return out
+
+
+def test_disc_rasteriser_matches_opencv_circle_golden_bitmaps():
+    """cv2.circle(radius=3, thickness=-1) (dataloader_sample.py:169; radius 6 in the line above it): the product's row
+    table against the committed bitmaps of drawing.cpp Circle() -- whole discs at r = 3 and r = 6 and r = 3 discs cut by
+    every border and corner, or lying outside (tests/golden/make_golden_circle.py; hand-checked rows in oracle/ref_circle.py)."""
+    import re
+    for name in ("circle_r3.txt", "circle_r6.txt", "circle_clipped.txt"):
+        for title, want in _read_bitmaps(name):
+            r, cx, cy = (int(v) for v in re.match(r"radius (\d+), centre \((-?\d+),(-?\d+)\)", title).groups())
+            img = np.zeros(want.shape, np.uint8)
+            P._draw_disc(img, cx, cy, P._disc_rows(r), value=1)
+            assert np.array_equal(img, want), title
+    assert int(_read_bitmaps("circle_r3.txt")[0][1].sum()) == 29 and int(_read_bitmaps("circle_r6.txt")[0][1].sum()) == 113
+
+
+def test_landmark_images_match_circle_restatement_everywhere():
+    """landmarks_to_images against oracle.ref_circle (Circle() restated with its `inside` and clipped branches): random
+    landmark sets incl. points on and beyond every border, both landmark formats, with and without the flip; radii 1..9."""
+    from oracle import ref_circle
+    rng = np.random.default_rng(5)
+    lm = rng.integers(-6, 262, size=(3, 68, 2))
+    lm[0, :8] = [[0, 0], [255, 255], [0, 255], [255, 0], [3, 3], [252, 252], [-3, 100], [100, 258]]
+    for flip in (False, True):
+        assert np.array_equal(P.landmarks_to_images(lm, flip=flip), ref_circle.landmarks_to_images(lm, flip=flip))
+    lm3 = rng.uniform(-1.05, 1.05, size=(2, 68, 3))
+    assert np.array_equal(P.landmarks_to_images(lm3, flip=True), ref_circle.landmarks_to_images(lm3, flip=True))
+    for r in range(1, 10):
+        for cx, cy in [(12, 12), (0, 3), (24, 24), (-r, 5), (5, 24 + r), (30, 30)]:
+            a, b = np.zeros((25, 25), np.uint8), np.zeros((25, 25), np.uint8)
+            P._draw_disc(a, cx, cy, P._disc_rows(r), value=255)
+            ref_circle.circle_filled(b, (cx, cy), r)
+            assert np.array_equal(a, b), (r, cx, cy)
