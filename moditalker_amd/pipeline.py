@@ -15,7 +15,7 @@ This is host logic (numpy / PIL for the image formats, torch for device tensors)
 `sample.py` itself is not importable (module-level argparse, hard-wired paths, cv2 / torchvision / omegaconf) and the disc
 rasteriser it uses, cv2.circle, is not installed here: `_disc_rows` produces the row spans of OpenCV's filled-circle scan
 conversion (modules/imgproc/src/drawing.cpp, Circle(), OpenCV 4.x).  It is checked bit for bit against golden bitmaps and
-against oracle/ref_circle.py, a statement-for-statement restatement of Circle() incl. its clipping path
+against the test suite's statement-for-statement restatement of Circle() incl. its clipping path
 (tests/test_pipeline_host.py); cv2 itself never ran here, see DESIGN.md section 4.
 """
 from __future__ import annotations
