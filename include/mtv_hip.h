@@ -141,6 +141,15 @@ int mtv_debug_stamps(mtv_ctx* ctx, int batch, const char* path, void* stream);
 /* Testing aid: plans built after this call run every eligible convolution on the LDS-tiled kernel k_conv_lds<wm, wn>
  * (wave tile 16 wm x 16 wn, workgroup 2 x 2 waves) instead of the tuned choice; wm = 0 switches it off again. */
 int mtv_debug_force_lds(int wm, int wn);
+/* Testing aid: plans built after this call run every eligible 1x1 convolution (the attention blocks' qkv / proj_out,
+ * unet.py:234,253) on the lean kernel k_lin<mt, nt, nwv> (wave tile 16 mt x 16 nt, nwv waves side by side along the
+ * output channels, whole K per wave; csrc/lin.hip) instead of the tuned choice; mt = 0 switches it off again. */
+int mtv_debug_force_lin(int mt, int nt, int nwv);
+/* Which attention core the UNet's self-attention launches take (head dim 16 / 32 / 64; process-wide, takes effect at the
+ * next launch / graph capture): 0 = the exact-f32 core k_attention everywhere (the default: it is the faster one on
+ * MI355X at every shape measured), 1 = the split-bf16 core k_attention_b3 (csrc/attn_b3.hip) on every eligible launch,
+ * -1 = k_attention_b3 for segments of >= 256 keys.  The parity tests run both. */
+int mtv_debug_attention_b3(int mode);
 
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
 int mtv_set_eager(mtv_ctx* ctx, int eager);

@@ -754,6 +754,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             double* dst = a.stat[t].sums + (size_t)(blockIdx.x & (STAT_COPIES - 1)) * a.stat_cstride + (((size_t)b * 3 + sgi) * 32 + g) * 2;
             atomicAdd(dst, s);
             atomicAdd(dst + 1, ss);
+            if (a.dbg_stat_dup) {
+                atomicAdd(dst + a.dbg_stat_dup, s);
+                atomicAdd(dst + a.dbg_stat_dup + 1, ss);
+            }
         }
     }
     MTV_STAMP(6);
@@ -1220,6 +1224,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
 }
 
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
+    if (t.NW == 64) return lin_smem_bytes(a);
     if (t.NW == 32) return lds_bytes_tiled(t.MT, t.NT, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
     return lds_bytes(t.MT, t.NT, t.NW, t.KS, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
 }
@@ -1301,6 +1306,11 @@ hipError_t conv_init_attrs() {
 
 hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
     ConvArgs a = a0;
+    // timing experiment (results unchanged): MTV_DEBUG_STATDUP=1 makes every workgroup issue its GroupNorm-statistics atomics a
+    // SECOND time, into the other step parity's arena (unused during this step, zeroed by this step's head conv): the step
+    // time it adds is what the real ones cost
+    static const bool stat_dup = getenv("MTV_DEBUG_STATDUP") != nullptr;
+    if (!stat_dup) a.dbg_stat_dup = 0;
     a.KS = t.KS;
     a.xmap = t.XM;
     if (a.KS > 1 && (!a.slab || !a.tickets || (a.N & 3))) return hipErrorInvalidValue;
@@ -1309,6 +1319,13 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
         a.xmap = 0;            // no padding blocks: every block of the grid takes part in the step hand-over
     }
     hipError_t e = hipErrorInvalidValue;
+    if (t.NW == 64) {            // lean 1x1 kernel (lin.hip)
+        if (conv_lin_eligible(a)) return launch_lin(a, t, s);
+        t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);   // (statistics targets are
+        t.KS = 1;                                                                                                       // attached after the op is created)
+        a.KS = 1;
+        a.xmap = t.XM;
+    }
     if (t.NW == 32 && !conv_lds_eligible(a)) {      // (statistics targets are attached after a plan's op is created)
         t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);
         t.KS = 1;

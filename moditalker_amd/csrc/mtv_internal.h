@@ -76,6 +76,7 @@ struct ConvArgs {
     int Lout, Lsrc, Lskip;   // tokens per batch element: output, tapped source, skip/residual source
     int B;
     const float* W;          // rows [ntaps*Cmain + Cskip][ldw], columns = output channels
+    const float* Wnk;        // 1x1 convs on identity rows only: the same weight as stored in the checkpoint, [N][Cmain] (k_lin, lin.hip)
     int ldw;
     int N;
     const float* bias;       // [N]
@@ -112,6 +113,7 @@ struct ConvArgs {
     const DdimFuse* ddim;    // sampler-step head only (nullptr otherwise)
     const int* step_counter; // ... the device-side step index (DdimFuse::counter; here too so it is loaded at entry)
     unsigned long long* dbg; // phase timestamps for tools/ubench/conv_bench (nullptr in the product)
+    long long dbg_stat_dup;  // 0 in the product: offset (doubles) of the other step parity's statistics arena (MTV_DEBUG_STATDUP timing experiment)
 };
 
 // Touch every 64-byte line of the kernel-argument block at kernel entry.  The compiler otherwise loads
@@ -253,6 +255,10 @@ __device__ __forceinline__ float ddim_update_elem(const DdimStep& st, float x, f
 // ---- launchers (kernels.hip) ----
 struct ConvTile { int MT, NT, NW, KS, XM; };   // XM: workgroup->tile mapping (0 rows fastest, 1 weight slice per XCD)
                                                // NW == 32: the LDS-tiled kernel k_conv_lds<WM = MT, WN = NT> (KS = 1, XM = 0)
+                                               // NW == 64: the lean 1x1 kernel k_lin<MT, NT, NWV = KS> (lin.hip; XM = 0)
+bool conv_lin_eligible(const ConvArgs& a);
+size_t lin_smem_bytes(const ConvArgs& a);
+hipError_t launch_lin(const ConvArgs& a, ConvTile t, hipStream_t s);
 bool conv_lds_eligible(const ConvArgs& a);
 ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has_gn);
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t);
@@ -262,6 +268,12 @@ hipError_t attn_init_attrs();
 hipError_t launch_gn_stats(const StatsArgs& a, hipStream_t s);
 hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// split-bf16 attention core (attn_b3.hip): the UNet's self-attention launches with head dim 16 / 32 / 64
+bool attn_b3_eligible(const AttnArgs& a);
+hipError_t launch_attention_b3(const AttnArgs& a, hipStream_t s);
+hipError_t attn_b3_init_attrs();
+extern int g_attn_b3_mode;          // -1 auto (segments of >= g_attn_b3_min_keys keys), 0 never, 1 every eligible launch (mtv_debug_attention_b3 / MTV_ATT_B3)
+extern int g_attn_b3_min_keys;
 hipError_t launch_linear(const LinearArgs& a, hipStream_t s);
 hipError_t launch_time_sinusoid(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
 hipError_t launch_pack_input(const float* x, const float* cond, const float* image_cond, int ic_len,

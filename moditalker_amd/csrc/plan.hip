@@ -252,7 +252,7 @@ struct Builder {
 
     static std::string conv_tag(const ConvArgs& a, const ConvTile& t) {
         char tag[80];
-        snprintf(tag, sizeof tag, "[%dx%d k%d t%d,%d,%d,%d%s]", a.Lout, a.N, a.ntaps * a.Cmain + a.Cskip, t.MT, t.NT, t.NW, t.KS, t.XM ? "x" : "");
+        snprintf(tag, sizeof tag, "[%dx%d k%d t%d,%d,%d,%d%s]", a.Lout, a.N, a.ntaps * a.Cmain + a.Cskip, t.MT, t.NT, t.NW, t.KS, t.XM ? "x" : "");   // (NW 32: k_conv_lds, NW 64: k_lin)
         return tag;
     }
 
@@ -260,6 +260,8 @@ struct Builder {
         a0.B = B;
         a0.seg_out = c->lv[lvl_out].seg();
         a0.stat_cstride = (unsigned)c->stats_copy_doubles;
+        if (mode == MODE_STEP0 || mode == MODE_STEP1)      // (timing experiment MTV_DEBUG_STATDUP, launch_conv: where the other parity's arena lies)
+            a0.dbg_stat_dup = (mode == MODE_STEP0 ? 1 : -1) * (long long)(c->stats_bytes / sizeof(double));
         static const bool geo_env = []() { const char* e = getenv("MTV_GEO"); return !e || atoi(e) != 0; }();
         if (c->geo_ok && geo_env) {                 // gather tables -> arithmetic (checked equal in mtv_create)
             const int lo = lvl_out;
@@ -472,17 +474,21 @@ struct Builder {
         const int ldq = pad64(3 * C);
         float* Wq = c->buf("w." + P + "qkv.weight", (size_t)C * ldq);
         wconv(P + "qkv.weight", 3 * C, C, 1, 1, true, Wq, ldq);
+        float* Wq_nk = c->buf("wnk." + P + "qkv.weight", (size_t)3 * C * C);      // the same weights as stored, [3C][C]: k_lin's operand
+        c->slots[c->slot_index[P + "qkv.weight"]].dst2 = Wq_nk;
         float* bq = c->wcopy(P + "qkv.bias", {3 * C});
         const int ldp = pad64(C);
         float* Wp = c->buf("w." + P + "proj_out.weight", (size_t)C * ldp);
         wconv(P + "proj_out.weight", C, C, 1, 1, true, Wp, ldp);
+        float* Wp_nk = c->buf("wnk." + P + "proj_out.weight", (size_t)C * C);
+        c->slots[c->slot_index[P + "proj_out.weight"]].dst2 = Wp_nk;
         float* bp = c->wcopy(P + "proj_out.bias", {C});
 
         double* site = c->new_site();
         add_stats({x}, lvl, site);
         float* qkv = c->act(nm + ".qkv", lvl, 3 * C);
         ConvArgs a{};
-        a.ntaps = 1; a.Lout = L.L; a.Lsrc = L.L; a.N = 3 * C; a.W = Wq; a.ldw = ldq; a.bias = bq; a.out = qkv;
+        a.ntaps = 1; a.Lout = L.L; a.Lsrc = L.L; a.N = 3 * C; a.W = Wq; a.Wnk = Wq_nk; a.ldw = ldq; a.bias = bq; a.out = qkv;
         a.nmain = 1; a.src[0] = x.p; a.C[0] = C; a.Cmain = C; a.seg_src = L.seg();
         a.gn = GnIn{site, gw, gb, nullptr, 0, C / 32, whole ? 1 : 0, 0, (unsigned)c->stats_copy_doubles};
         add_conv(a, nm + ".qkv", lvl);
@@ -506,7 +512,7 @@ struct Builder {
         double aflops = 0.0;
         for (int i = 0; i < t.nseg; ++i) aflops += 4.0 * B * H * (double)t.seg_len[i] * t.seg_len[i] * d;
         char tag[64];
-        snprintf(tag, sizeof tag, "[L%d d%d %s]", L.L, d, whole ? "1d" : "2d");
+        snprintf(tag, sizeof tag, "[L%d d%d %s]", L.L, d, whole ? "1d" : "2d");      // (which core runs is decided at launch: launch_attention)
         static const bool att_stamps = getenv("MTV_STAMPS") != nullptr;       // diagnostic build only (mtv_debug_stamps)
         if (att_stamps) {
             t.dbg = reinterpret_cast<unsigned long long*>(c->buf("dbg.attn." + nm + "." + std::to_string(mode) + "." + std::to_string(B), 128));
@@ -517,7 +523,7 @@ struct Builder {
         Tens out;
         out.lvl = lvl; out.C = C; out.p = c->act(nm + ".out", lvl, C);
         ConvArgs p{};
-        p.ntaps = 1; p.Lout = L.L; p.Lsrc = L.L; p.Lskip = L.L; p.N = C; p.W = Wp; p.ldw = ldp; p.bias = bp; p.out = out.p;
+        p.ntaps = 1; p.Lout = L.L; p.Lsrc = L.L; p.Lskip = L.L; p.N = C; p.W = Wp; p.Wnk = Wp_nk; p.ldw = ldp; p.bias = bp; p.out = out.p;
         p.nmain = 1; p.src[0] = att; p.C[0] = C; p.Cmain = C; p.seg_src = L.seg();
         p.res = x.p;
         add_conv(p, nm + ".proj", lvl);
@@ -656,7 +662,16 @@ struct Builder {
 // testing aid: MTV_FORCE_LDS="WM,WN" (or mtv_debug_force_lds) runs every eligible conv of plans built afterwards on the
 // LDS-tiled kernel k_conv_lds<WM, WN>; a conv that turns out not to be eligible at launch falls back (launch_conv)
 static int g_force_wm = -1, g_force_wn = 0;
+static int g_force_lin[3] = {-1, 0, 0};     // MTV_FORCE_LIN="MT,NT,NWV" (or mtv_debug_force_lin): every eligible 1x1 conv on k_lin<MT, NT, NWV>
 void force_lds_tile(const ConvArgs& a, ConvTile* t) {
+    if (g_force_lin[0] == -1) {
+        g_force_lin[0] = 0;
+        if (const char* e = getenv("MTV_FORCE_LIN")) {
+            int x = 0, y = 0, z = 0;
+            if (sscanf(e, "%d,%d,%d", &x, &y, &z) == 3 && (x == 1 || x == 2) && (y == 1 || y == 2 || y == 4) && (z == 1 || z == 2 || z == 4)) { g_force_lin[0] = x; g_force_lin[1] = y; g_force_lin[2] = z; }
+        }
+    }
+    if (g_force_lin[0] > 0 && conv_lin_eligible(a)) { *t = ConvTile{g_force_lin[0], g_force_lin[1], 64, g_force_lin[2], 0}; return; }
     if (g_force_wm == -1) {
         g_force_wm = 0;
         if (const char* e = getenv("MTV_FORCE_LDS")) {
@@ -747,7 +762,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     p->tuned = true;
     tune_cache_load(c);
     const char* env = getenv("MTV_AUTOTUNE");
-    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0) return MTV_OK;
+    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0 || g_force_lin[0] > 0) return MTV_OK;
     static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
     struct Events {             // destroyed on every exit path (HIPCHK returns early)
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -777,11 +792,12 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const ConvTile& t = it->second;
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
             const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
-            const bool shape_ok = tiled_ok ||
+            const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
+            const bool shape_ok = tiled_ok || lin_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
                                    t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1));
-            if (!shape_ok || (!tiled_ok && t.NW * t.KS > nchunks) || (t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
+            if (!shape_ok || (!tiled_ok && !lin_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
                 conv_smem_bytes(a, t) > 120 * 1024) {
                 c->tune_cache.erase(it);
                 it = c->tune_cache.end();
@@ -859,6 +875,31 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                         best = t;
                     }
                 }
+            }
+            // the lean 1x1 kernel (lin.hip): wave tile 16 MT x 16 NT, NWV waves side by side along N, whole K per wave
+            if (conv_lin_eligible(a)) {
+                for (int MT = 1; MT <= 2; ++MT)
+                    for (int NT = 1; NT <= 4; NT *= 2)
+                        for (int NWV = 1; NWV <= 4; NWV *= 2) {
+                            if (MT == 2 && a.Lout < 32) continue;
+                            if (16 * NT * NWV > a.N && NWV > 1) continue;           // wider than the layer
+                            const ConvTile t{MT, NT, 64, NWV, 0};
+                            float samp[16];
+                            HIPCHK(launch_conv(a, t, s));
+                            for (int w = 0; w < nsamp; ++w) {
+                                HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
+                                HIPCHK(hipEventRecord(e0, s));
+                                HIPCHK(launch_conv(a, t, s));
+                                HIPCHK(hipEventRecord(e1, s));
+                                HIPCHK(hipEventSynchronize(e1));
+                                HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
+                            }
+                            std::sort(samp, samp + nsamp);
+                            if (samp[nsamp / 2] < best_ms) {
+                                best_ms = samp[nsamp / 2];
+                                best = t;
+                            }
+                        }
             }
             it = c->tune_cache.emplace(key, best).first;
             tune_cache_append(key, best);
@@ -1081,6 +1122,7 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
         const int N = (int)s.shape[0], C = (int)s.shape[1];
         const int ntaps = (int)(n / ((size_t)N * C));
         HIPCHK(launch_repack_conv(c->staging, s.dst, N, C, ntaps, s.ld, nullptr));
+        if (s.dst2) HIPCHK(hipMemcpyAsync(s.dst2, c->staging, n * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
         HIPCHK(hipStreamSynchronize(nullptr));
     }
     s.loaded = true;
@@ -1400,6 +1442,19 @@ int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up)
     if (res <= 0 || frames <= 0 || tok < 0 || tok >= res * res + 2 * frames * res || ky < 0 || ky > 2 || kx < 0 || kx > 2)
         return fail(MTV_ERR_INVALID, "debug_gather_index: bad arguments") - 1;   // (-2: distinct from "padding")
     return geo_source(res, frames, tok, ky, kx, up != 0);
+}
+
+int mtv_debug_attention_b3(int mode) {
+    if (mode < -1 || mode > 1) return fail(MTV_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (every eligible launch)");
+    g_attn_b3_mode = mode;
+    return MTV_OK;
+}
+
+int mtv_debug_force_lin(int mt, int nt, int nwv) {
+    if (mt == 0) { g_force_lin[0] = 0; return MTV_OK; }
+    if (!((mt == 1 || mt == 2) && (nt == 1 || nt == 2 || nt == 4) && (nwv == 1 || nwv == 2 || nwv == 4))) return fail(MTV_ERR_INVALID, "k_lin tile must be {1,2} x {1,2,4} x {1,2,4}");
+    g_force_lin[0] = mt; g_force_lin[1] = nt; g_force_lin[2] = nwv;
+    return MTV_OK;
 }
 
 int mtv_debug_force_lds(int wm, int wn) {

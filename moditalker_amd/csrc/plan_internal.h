@@ -49,6 +49,7 @@ struct WSlot {
     int ld;         // ROLE_CONV: leading dimension (padded output channels)
     bool loaded;
     int aux = 0;    // ROLE_QKV_HEADS: head dim; ROLE_REPEAT: repeat count
+    float* dst2 = nullptr;   // ROLE_CONV, 1x1 only: a second copy in the checkpoint's own layout [N][C] (k_lin, lin.hip)
 };
 
 struct Tens {
@@ -247,4 +248,4 @@ int run_ops(mtv_ctx* c, Plan* p, hipStream_t s);
 int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out);
 int check_ready(mtv_ctx* c, int batch);
 int ctx_init_common(mtv_ctx* c);
-void force_lds_tile(const ConvArgs& a, ConvTile* t);    // MTV_FORCE_LDS testing aid                           // device, capture stream, kernel attributes
+void force_lds_tile(const ConvArgs& a, ConvTile* t);    // MTV_FORCE_LDS / MTV_FORCE_LIN testing aids

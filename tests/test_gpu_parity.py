@@ -325,3 +325,65 @@ def test_lds_tiled_conv_kernel_vs_reference_golden(wm, wn):
         assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
     finally:
         lib.mtv_debug_force_lds(0, 0)
+
+
+@pytest.mark.parametrize("mt,nt,nwv", [(1, 1, 4), (1, 2, 2), (1, 4, 1), (2, 1, 2), (2, 2, 4), (2, 4, 2)])
+def test_lean_1x1_kernel_vs_reference_golden(mt, nt, nwv):
+    """k_lin (csrc/lin.hip: whole K per wave, weight in the checkpoint's [N][K] layout, epilogue from the accumulators)
+    forced onto every eligible qkv / proj_out conv: base UNet eps vs the reference golden at t = 999 / 0, the narrow
+    model's taps (group size 1: the statistics-producing proj convs must fall back to k_conv there), and a ragged
+    2-clip geometry (row tiles straddling plane boundaries, partial tiles) vs the oracle."""
+    from moditalker_amd import _lib
+    from oracle import ref_unet
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_force_lin(mt, nt, nwv), "mtv_debug_force_lin")
+    try:
+        g = np.load(os.path.join(GOLDEN, "base.npz"))
+        net = _build(BASE_CFG, 7, max_batch=1)
+        dev = _dev()
+        x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+        for tv in (999, 0):
+            eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
+            assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
+        names = [p["name"] for p in net.diffusion_model.profile_forward(1, 1, dev)]
+        assert sum(f"t{mt},{nt},64,{nwv}]" in n for n in names) >= 60, "the lean kernel was not selected"
+        cfg = dict(BASE_CFG, image_size=24)            # 24x24 | 8x24 | 8x24 planes: ragged tiles at every level
+        net2 = _build(cfg, 21, frames=8, max_batch=2)
+        x, cond, ic = filler.synthetic_inputs(2, 24, 8, seed=5, tag="lds")
+        t = torch.tensor([700, 3])
+        ref = ref_unet.unet_forward({k: v.cpu() for k, v in net2.state_dict().items()}, cfg, x, cond, ic, t, 24, 8)
+        assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
+    finally:
+        lib.mtv_debug_force_lin(0, 0, 0)
+
+
+def test_split_bf16_attention_core_vs_reference_golden():
+    """k_attention_b3 (csrc/attn_b3.hip: QK^T and PV on v_mfma_f32_16x16x32_bf16 through a three-term bf16 split) forced onto
+    EVERY self-attention launch of the base UNet: eps vs the reference golden at t = 999 / 500 / 0, the metric's own 250-step
+    sample and the noised-start sample vs the reference golden, and a ragged 2-clip geometry (partial key blocks, partial
+    query tiles) vs the oracle."""
+    from moditalker_amd import _lib
+    from oracle import ref_unet
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_attention_b3(1), "mtv_debug_attention_b3")
+    try:
+        g = np.load(os.path.join(GOLDEN, "base.npz"))
+        net = _build(BASE_CFG, 7, max_batch=1)
+        dev = _dev()
+        x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+        for tv in (999, 500, 0):
+            eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
+            assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
+        for S in (4, 250):
+            noise = filler.noise_list(S, (1, 4, 2048), seed=7, tag=f"base.S{S}")
+            dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=S, w=0.0).to(dev)
+            z = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=[n.to(dev) for n in noise])
+            assert _maxabs(z, g[f"sample_S{S}"]) <= SAMPLE_TOL, S
+        cfg = dict(BASE_CFG, image_size=24)            # 24x24 | 8x24 | 8x24 planes: segments of 576 / 192 / 960 keys ... down to 9 / 3
+        net2 = _build(cfg, 21, frames=8, max_batch=2)
+        x, cond, ic = filler.synthetic_inputs(2, 24, 8, seed=5, tag="lds")
+        t = torch.tensor([700, 3])
+        ref = ref_unet.unet_forward({k: v.cpu() for k, v in net2.state_dict().items()}, cfg, x, cond, ic, t, 24, 8)
+        assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
+    finally:
+        lib.mtv_debug_attention_b3(0)

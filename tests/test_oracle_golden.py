@@ -141,3 +141,21 @@ def test_cross_attention_oracle_vs_reference_golden():
         if cd:
             mask = torch.from_numpy(g[f"{tag}_mask"])
             assert float((ref_xattn.cross_attention(sd, x, ctx, mask, H) - torch.from_numpy(g[f"{tag}_out_masked"])).abs().max()) <= 2e-6
+
+
+def test_split_bf16_attention_emulation():
+    """The split-bf16 attention core (csrc/attn_b3.hip: q, k, v as three bf16 terms, p as two, six / five partial products)
+    keeps fp32-class accuracy: against an fp64 evaluation its error stays within 4x of plain fp32's (a few 1e-6) on head dims 16 / 32 / 64."""
+    from oracle import ref_attn_b3
+    torch.manual_seed(0)
+    for L, d in ((1024, 16), (512, 32), (128, 64)):
+        q, k, v = torch.randn(4, L, d) * 1.5, torch.randn(4, L, d) * 1.5, torch.randn(4, L, d)
+        sc = d ** -0.25
+        w64 = torch.softmax((q.double() * sc) @ (k.double() * sc).transpose(-1, -2), -1) @ v.double()
+        w32 = torch.softmax((q * sc) @ (k * sc).transpose(-1, -2), -1) @ v
+        e32 = float((w32.double() - w64).abs().max())
+        eb3 = float((ref_attn_b3.attention_split_bf16(q, k, v).double() - w64).abs().max())
+        assert eb3 <= 4.0 * e32 + 1e-6, (L, d, e32, eb3)
+        # a ONE-term probability (plain bf16 P) would not do: three orders of magnitude worse
+        p1 = ref_attn_b3.split_terms(torch.softmax((q * sc) @ (k * sc).transpose(-1, -2), -1), 1)[0] @ v
+        assert float((p1.double() - w64).abs().max()) > 50 * e32
