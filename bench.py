@@ -55,6 +55,28 @@ def cycled_steps(dm, K):
                            seq, dm.ddim_sampling_eta)
 
 
+def bind_to_gpu_numa_node(dev):
+    """Pin this process to the CPUs of the NUMA node its GPU hangs off (8 ranks each replaying ~430 graphs/s from the host
+    is where clip-sharded scaling can be lost to cross-socket launches).  Best effort: returns what was done, never raises."""
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return dict(numa_node=node, bound=False, why="no NUMA affinity reported for the device")
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return dict(numa_node=node, bound=False, why="node's CPUs are outside this process's cpuset")
+        os.sched_setaffinity(0, cpus)
+        return dict(numa_node=node, bound=True, cpus=len(cpus), pci=bdf)
+    except (OSError, ValueError, AttributeError) as e:
+        return dict(bound=False, why=f"{type(e).__name__}: {e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +109,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    affinity = bind_to_gpu_numa_node(dev) if os.environ.get("MTV_BENCH_NO_BIND") != "1" else dict(bound=False, why="MTV_BENCH_NO_BIND=1")
     # (MTV_BENCH_FORCE_DIST=1: go through the RCCL path with a single rank too -- a self-test of the N>1 code)
     use_dist = world > 1 or os.environ.get("MTV_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -135,14 +158,31 @@ def main():
     xt = x.clone()
     t0 = time.perf_counter()
     run(K, xt)
+    t_own = None
     if use_dist:                                  # final gather of the finished latents (32 KiB each)
+        torch.cuda.synchronize(dev)               # (splits the timed region into this rank's K steps | the gather; costs one host sync)
+        t_own = time.perf_counter() - t0
         out = [torch.empty_like(xt) for _ in range(world)]
         dist.all_gather(out, xt)
     barrier()
     dt = time.perf_counter() - t0
+    if t_own is None:
+        t_own = dt
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist_info = None
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # what every rank measured: its own K steps, and the whole region incl. the gather + closing barrier
+        mine = torch.tensor([t_own, dt], device=dev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        own = sorted(1e3 * float(v[0]) / K for v in allr)
+        dist_info = dict(backend=dist.get_backend(), world_size_reported=dist.get_world_size(), visible_gpus=torch.cuda.device_count(),
+                         per_rank_ms_per_step=dict(min=round(own[0], 4), median=round(own[len(own) // 2], 4), max=round(own[-1], 4)),
+                         gather_and_barrier_ms=round(1e3 * max(float(v[1]) - float(v[0]) for v in allr), 3),
+                         latents_gathered=[bool(torch.isfinite(o).all()) for o in out].count(True),
+                         note="per_rank_ms_per_step = each rank's own K steps (host-synchronised before the gather); "
+                              "`value` uses the max over ranks of the whole region, gather and closing barrier included")
     dt = float(tmax.item())
     assert torch.isfinite(xt).all()
 
@@ -348,12 +388,16 @@ def main():
             "steps": K,
             "warmup": W,
             "ramp_steps_untimed": args.ramp_steps,
+            "steps_sampled": f"the first {K} steps of the 250-step DDIM schedule (the network's work does not depend on the step index)"
+                             if K <= 250 else f"{K} steps cycling through the 250-step DDIM schedule",
             "ms_per_step": round(1e3 * dt / K, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (random-init weights incl. zero-init tensors, U(-1,1) cond latents, N(0,1) noise)",
+            "distributed": dist_info,
+            "cpu_affinity": affinity,
             "config": {"workload": f"configs[{1 if R == 32 else 3}]: 16-frame {8 * R}x{8 * R} clip = tri-plane latent [1,4,{L}] (R={R},T=16), "
                                    "base second-stage UNet (132.2M live params), DDIM eta=1, 250-step schedule, B=1 per GPU",
                        "clips": world, "parallelism": f"clip-sharded x{world}, all_gather of latents at the end"},

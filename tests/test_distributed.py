@@ -167,3 +167,26 @@ def test_rccl_world1_real_sampler_matches_unsharded():
         assert torch.equal(got[0], mark)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_py_distributed_path_single_rank():
+    """bench.py's own N > 1 code path (RCCL init, per-rank timing gather, final all_gather of the latents, NUMA binding),
+    exercised as far as one GPU allows: MTV_BENCH_FORCE_DIST=1 runs it with a world of one rank.  The driver's 8-GPU
+    scaling run then only adds ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MTV_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "2", "--ramp-steps", "10",
+                        "--no-cpu-baseline", "--batched-clips", "0", "--no-autoencoder", "--profile-iters", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and d["steps"] == 12
+    di = d["distributed"]
+    assert di["backend"] == "nccl" and di["world_size_reported"] == 1 and di["latents_gathered"] == 1
+    assert 0 < di["per_rank_ms_per_step"]["min"] <= di["per_rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.001
+    assert di["gather_and_barrier_ms"] >= 0 and "cpu_affinity" in d and "steps_sampled" in d

@@ -180,3 +180,54 @@ def test_config4_full_size_sampler_then_decode_vs_oracle():
     assert float((z.cpu() - zr).abs().max()) <= TOL
     mse = float(((frames - fr) ** 2).mean())
     assert mse <= 1e-8 and float((frames - fr).abs().max()) <= TOL, (mse, float((frames - fr).abs().max()))
+
+
+def test_config4_full_size_through_conditioning_vs_oracle(tmp_path):
+    """BASELINE configs[4] end to end at its own geometry, starting from the files the pipeline starts from: aligned landmark
+    .npy files -> landmarks_to_images (cv2.circle restated) -> the four 256x256 extracts of sample.py:328-331 (RGB autoencoder
+    for x, x_ref, masked_x; landmark autoencoder for x_l) -> cat -> base second-stage UNet sampler -> decode_from_sample ->
+    8-bit frames, through moditalker_amd.pipeline.MToVSampler on the HIP kernels, against the same composition built from
+    the CPU oracle's pieces (and the landmark images against oracle/ref_circle.py).  4 DDIM steps keep the oracle side near a
+    minute on the GPU box's host; the 250-step schedule is pinned by test_base_sampler_vs_reference_golden."""
+    from conftest import BASE_CFG
+    from moditalker_amd import pipeline as P
+    from oracle import ref_ae, ref_circle, ref_ddpm, ref_unet
+    dev = _dev()
+    R, T, S, res = 32, 16, 4, 256
+    net = DiffusionWrapper(UNetModel(**BASE_CFG, frames=T, max_batch=1)).eval()
+    filler.fill_module_(net, seed=7, skip_prefixes=("output_bg_",))
+    sd_u = {k: v.clone() for k, v in net.state_dict().items() if "output_bg_" not in k}
+    net = net.to(dev)
+    ae, ae_l = _ae(res, 22), _ae(res, 23)                    # two checkpoints of one architecture (sample.py:206-218)
+    sd_a = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
+    sd_l = {k: v.detach().cpu() for k, v in ae_l.state_dict().items()}
+    L = R * R + 2 * T * R
+    # ---- the on-disk inputs: aligned_npy/<id>/NNNNN.npy, one [68, 2] array per frame (align_face_recon.py:347)
+    rng = np.random.default_rng(11)
+    base = np.stack([[60 + 2.1 * i, 70 + 1.7 * ((i * 7) % 68)] for i in range(68)])
+    for f in range(5, 5 + T):
+        np.save(tmp_path / f"{str(f).zfill(5)}.npy", base + rng.normal(0, 1.5, size=(68, 2)) + f)
+    lm = P.load_aligned_landmarks(str(tmp_path), 5, T)
+    img_l = P.landmarks_to_images(lm, WH=256)
+    assert np.array_equal(img_l, ref_circle.landmarks_to_images(lm, WH=256)) and img_l.any()
+    vid = ((filler.uniform_pm1("cfg4c.vid", (1, T, 3, res, res), 7) + 1) * 127.5).round()
+    ref = vid[:, :1].expand(-1, T, -1, -1, -1).contiguous()
+    x_l = torch.from_numpy(img_l).float().permute(0, 3, 1, 2)[None].contiguous()
+    masked = torch.from_numpy(np.stack([P.crop_lower_half(vid[0, f].numpy(), lm[f]) for f in range(T)])).float()[None]
+    noise = filler.noise_list(S, (1, 4, L), seed=7, tag="cfg4c.noise")
+    dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+    sampler = P.MToVSampler(dm, ae, ae_l, latent_res=R)
+    cond = sampler.conditioning(*(t.to(dev) for t in (ref, vid, x_l, masked)))
+    z, fake = sampler.sample_chunk(cond, noise=[n.to(dev) for n in noise])
+    u8 = P.frames_to_uint8(fake)
+    # ---- the oracle composition
+    xr, xv, xl, xm = (P.to_model_range(t) for t in (ref, vid, x_l, masked))
+    ic_r = ref_ae.extract(sd_a, xr)[:, :, :R * R]
+    c_r = torch.cat([ref_ae.extract(sd_l, xl), ref_ae.extract(sd_a, xm)], dim=1)
+    assert float((cond["image_cond"].cpu() - ic_r).abs().max()) <= TOL and float((cond["c"].cpu() - c_r).abs().max()) <= TOL
+    zr = ref_ddpm.ddim_sample(lambda a, b, c, d: ref_unet.unet_forward(sd_u, BASE_CFG, a, b, c, d, R, T), c_r, ic_r, noise, S)
+    fr = (1 + ref_ae.decode_from_sample(sd_a, zr, res, T).clamp(-1, 1).reshape(1, T, 3, res, res).permute(0, 1, 3, 4, 2)) * 127.5
+    assert float((z.cpu() - zr).abs().max()) <= TOL
+    assert float(((fake - fr) / 127.5).abs().max()) <= TOL
+    d = np.abs(u8.astype(np.int32) - fr.to(torch.uint8).numpy().astype(np.int32))
+    assert u8.shape == (1, T, res, res, 3) and d.max() <= 1 and d.mean() <= 0.01, (int(d.max()), float(d.mean()))

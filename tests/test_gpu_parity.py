@@ -387,3 +387,35 @@ def test_split_bf16_attention_core_vs_reference_golden():
         assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
     finally:
         lib.mtv_debug_attention_b3(0)
+
+
+def test_batched_eight_clip_plan_vs_reference_golden():
+    """The B = 8 plan bench.py's `batched_info` times (its own tiles: k_conv_lds on the large convs, small key blocks in the
+    attention), untouched by any forcing: clips 0, 2, 4, 6 carry the reference golden's inputs and noise and must reproduce
+    the reference's 4-step sample and eps; clips 1, 3, 5, 7 carry a different clip (other inputs, other noise), checked
+    against the oracle -- so a clip read or written at the wrong batch offset cannot pass."""
+    from oracle import ref_ddpm, ref_unet
+    g = np.load(os.path.join(GOLDEN, "base.npz"))
+    B, S, L = 8, 4, 2048
+    net = _build(BASE_CFG, 7, max_batch=B)
+    dev = _dev()
+    sd = {k: v.cpu() for k, v in net.state_dict().items() if "output_bg_" not in k}
+    xa, ca, ia = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+    xb, cb, ib = filler.synthetic_inputs(1, 32, 16, seed=19, tag="b8.other")
+    pick = lambda a, b: torch.cat([a if k % 2 == 0 else b for k in range(B)], dim=0)
+    x, cond, ic = pick(xa, xb), pick(ca, cb), pick(ia, ib)
+    t = torch.tensor([999 if k % 2 == 0 else 321 for k in range(B)])
+    eps = net(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)).cpu()
+    eps_b = ref_unet.unet_forward(sd, BASE_CFG, xb, cb, ib, torch.tensor([321]), 32, 16)
+    for k in range(B):
+        assert _maxabs(eps[k:k + 1], g["eps_t999"] if k % 2 == 0 else eps_b) <= FWD_TOL, k
+    names = [p["name"] for p in net.diffusion_model.profile_forward(B, 1, dev)]
+    assert any(",32,1]" in n for n in names), "the batched plan is expected to use the LDS-tiled conv kernel somewhere"
+    na = filler.noise_list(S, (1, 4, L), seed=7, tag=f"base.S{S}")
+    nb = filler.noise_list(S, (1, 4, L), seed=19, tag="b8.other.noise")
+    noise = [pick(a, b).to(dev) for a, b in zip(na, nb)]
+    dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=S, w=0.0).to(dev)
+    z = dm.sample(batch_size=B, cond=cond.to(dev), image_cond=ic.to(dev), noise=noise).cpu()
+    zb = ref_ddpm.ddim_sample(lambda a, b, c, d: ref_unet.unet_forward(sd, BASE_CFG, a, b, c, d, 32, 16), cb, ib, nb, S)
+    for k in range(B):
+        assert _maxabs(z[k:k + 1], g[f"sample_S{S}"] if k % 2 == 0 else zb) <= SAMPLE_TOL, k
