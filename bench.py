@@ -221,13 +221,16 @@ def main():
         # HBM bytes per launch from the PMC passes (cannot be collected inside this process): the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this same command, gfx950 correction applied
         # (a constant of the committed profile, NOT a measurement of this run: `traffic_source.kind` says so)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc, hbm_counter_GBs = None, None, {}, None
         try:
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
             e = pmc[dom_name]
             traffic = round((2.0 * e["fetch_raw_MB_per_step"] + e["write_raw_MB_per_step"]) * 1e6 / e["launches_per_step"])
             traffic_src = dict(kind="committed", collected=pmc.get("collected"), commit=pmc.get("commit"), detail=pmc["source"])
-        except (OSError, KeyError, ValueError):
+            # counter bytes of the conv family (committed PMC passes) over THIS run's family time
+            ec = pmc["k_conv"]
+            hbm_counter_GBs = round((2.0 * ec["fetch_raw_MB_per_step"] + ec["write_raw_MB_per_step"]) * 1e6 / (conv["ms"] * 1e-3) / 1e9, 1)
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
         roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TF,
                         unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TF, 4), traffic=traffic, traffic_unit="bytes/launch",
@@ -236,7 +239,10 @@ def main():
                         avg_launch_us_with_event_overhead=round(1e3 * dom["ms_raw"] / max(1, dom["launches"]), 3),
                         event_overhead_us_per_launch=round(1e3 * ev_ms, 3),
                         algorithmic_bytes_per_launch=round(dom["bytes"] / max(1, dom["launches"])),
-                        flops_per_step=dom["flops"])
+                        flops_per_step=dom["flops"],
+                        hbm_counter_GBs=hbm_counter_GBs,            # conv family: (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes) / this run's family time
+                        mfma_util_counter=pmc.get("k_conv", {}).get("mfma_util"),   # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles (committed PMC pass, tools/pmc_util.py)
+                        counter_kind="committed")
         # the HBM side of the same family, with BOTH byte definitions: SURVEY section 8(d)'s "fused conv/GN path"
         # (3x3 conv weights + fused 1x1 skip weights + their activations: 477 MB at configs[1]) and this build's wider
         # one (every k_conv launch incl. qkv/proj: weights once + activations in/out once)
@@ -380,6 +386,8 @@ def main():
         attn_roof = dict(bound="mfma", kernel="k_attention", achieved=round(attn["flops"] / (attn["ms"] * 1e-3) / 1e12, 3) if attn["ms"] else 0.0,
                          peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches_per_step=attn["launches"], flops_per_step=attn["flops"])
         attn_roof["frac"] = round(attn_roof["achieved"] / MFMA_F32_PEAK_TF, 4)
+        attn_roof["mfma_util_counter"] = pmc.get("k_attention", {}).get("mfma_util")   # matrix-pipe busy fraction from SQ counters (committed pass)
+        attn_roof["counter_kind"] = "committed"
         result = {
             "metric": f"denoise-steps/sec (16-frame {8 * R}^2 clip, 250 DDIM steps)",
             "value": round(world * K / dt, 3),

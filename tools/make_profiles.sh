@@ -29,6 +29,19 @@ PF=$(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 PW=$(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 NL=$(grep -m1 -oE '^# [0-9]+ launches' $O/r${NN}_per_launch_hipevents.txt | grep -oE '[0-9]+')
 python tools/summarize_profile.py $KT --launches $NL ${PF:+--fetch $PF} ${PW:+--write $PW} > $O/r${NN}_step_summary.txt 2>&1
+python tools/per_op_traffic.py $O/r${NN}_per_launch_hipevents.txt $PF $PW --out $O/r${NN}_per_op_traffic.txt > /dev/null 2>&1
+# 5b. matrix-pipe / VALU utilisation counters (one more PMC pass, SQ + GRBM blocks only) -> MFMA utilisation per kernel family,
+#     and the counter-based GB/s of the conv family (north_star: "rocprof counters reporting achieved HBM GB/s ... and MFMA utilisation")
+MTV_EAGER=1 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE \
+    --output-format csv -d $O/pmc_SQ -o p -- python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_SQ.log 2>&1
+echo "pmc SQ rc=$?"
+PS=$(find $O/pmc_SQ -name '*counter_collection.csv' | head -1)
+python tools/pmc_util.py $PS --launches $NL --fetch $PF --write $PW --trace $KT --json $O/pmc_util.json > $O/r${NN}_pmc_util.txt 2>&1
+# 5c. does --pmc survive a hipGraph replay on this image?  (round 2: segfault at the first replay.)  One short try, graph mode.
+timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_graph -o p -- \
+    python bench.py --steps 10 --warmup 2 --ramp-steps 5 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_graph.log 2>&1
+echo "pmc on the graph path: rc=$? ($(find $O/pmc_graph -name '*counter_collection.csv' | wc -l) counter files)" | tee -a $O/r${NN}_pmc_util.txt
+rm -rf $O/pmc_SQ $O/pmc_graph
 # 6. configs[3] (R=64), informational
 timeout 300 python bench.py --res 64 --steps 40 --warmup 10 --no-cpu-baseline --batched-clips 0 > /dev/null 2>&1
 timeout 300 python bench.py --res 64 --steps 150 --warmup 15 --no-cpu-baseline --batched-clips 0 > $O/r${NN}_bench_res64_n1.json 2>/dev/null
