@@ -68,11 +68,12 @@ def bind_to_gpu_numa_node(dev):
         for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
             lo, _, hi = part.partition("-")
             cpus.update(range(int(lo), int(hi or lo) + 1))
-        cpus &= os.sched_getaffinity(0)
+        before = os.sched_getaffinity(0)
+        cpus &= before
         if not cpus:
             return dict(numa_node=node, bound=False, why="node's CPUs are outside this process's cpuset")
         os.sched_setaffinity(0, cpus)
-        return dict(numa_node=node, bound=True, cpus=len(cpus), pci=bdf)
+        return dict(numa_node=node, bound=True, cpus=len(cpus), pci=bdf, _before=sorted(before))
     except (OSError, ValueError, AttributeError) as e:
         return dict(bound=False, why=f"{type(e).__name__}: {e}")
 
@@ -265,6 +266,8 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ref_ddpm, ref_unet
+            if affinity.get("bound"):             # the CPU baseline uses the whole box, not the GPU's NUMA node
+                os.sched_setaffinity(0, affinity["_before"])
             ncores = max(1, (os.cpu_count() or 2) // 2)
             sd = {k: v.detach().cpu() for k, v in net.state_dict().items() if "output_bg_" not in k}
             cfg = dict(BASE_UNET_CONFIG)
@@ -405,7 +408,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (random-init weights incl. zero-init tensors, U(-1,1) cond latents, N(0,1) noise)",
             "distributed": dist_info,
-            "cpu_affinity": affinity,
+            "cpu_affinity": {k: v for k, v in affinity.items() if not k.startswith("_")},
             "config": {"workload": f"configs[{1 if R == 32 else 3}]: 16-frame {8 * R}x{8 * R} clip = tri-plane latent [1,4,{L}] (R={R},T=16), "
                                    "base second-stage UNet (132.2M live params), DDIM eta=1, 250-step schedule, B=1 per GPU",
                        "clips": world, "parallelism": f"clip-sharded x{world}, all_gather of latents at the end"},
