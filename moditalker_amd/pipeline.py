@@ -121,6 +121,36 @@ def save_frames(start_iter: int, frames_u8: np.ndarray, folder: str) -> List[str
     return names
 
 
+def save_gif(frames_u8: np.ndarray, fname: str, duration_ms: int = 100) -> str:
+    """sample.py:55-76 save_image_grid's output format: frames_u8 [T, H, W, 3] -> an animated GIF (PIL: `save_all`, 100 ms per
+    frame, loop forever, the reference's arguments)."""
+    from PIL import Image
+    imgs = [Image.fromarray(f, "RGB") for f in frames_u8]
+    imgs[0].save(fname, quality=95, save_all=True, append_images=imgs[1:], duration=duration_ms, loop=0)
+    return fname
+
+
+def make_video(result_frames, audio_path: Optional[str], save_path: str, fps: int = 25) -> str:
+    """sample.py:107-116: frames -> <save_path minus .mp4>no_audio.mp4 (imageio / ffmpeg writer at `fps`), then ffmpeg muxes the
+    driving audio in (`-map 0:v -map 1:a -c:v copy -shortest`) and the silent file is removed.  Host-only and after the path;
+    imageio and the ffmpeg binary are the reference's own dependencies and are not part of this image: without them this raises
+    a RuntimeError that says so (no silent fallback), `audio_path=None` skips the mux."""
+    import shutil
+    import subprocess
+    try:
+        import imageio
+    except ImportError as e:
+        raise RuntimeError("make_video needs imageio (+ imageio-ffmpeg), as MToV/sample.py does; PNG frames and GIFs need only PIL") from e
+    silent = save_path.replace(".mp4", "no_audio.mp4") if audio_path else save_path
+    imageio.mimwrite(silent, list(result_frames), fps=fps, output_params=["-vf", f"fps={fps}"])
+    if audio_path:
+        if shutil.which("ffmpeg") is None:
+            raise RuntimeError("make_video: the ffmpeg binary is needed to mux the audio track (sample.py:110-113)")
+        subprocess.run(["ffmpeg", "-y", "-i", silent, "-i", audio_path, "-map", "0:v", "-map", "1:a", "-c:v", "copy", "-shortest", save_path], check=True)
+        os.remove(silent)
+    return save_path
+
+
 def last_frame_to_uint8(fake: torch.Tensor) -> np.ndarray:
     """sample.py:391-398: the last frame of every clip as stored in references/<n>/<idx>.png: rint, clip, uint8
     (the BGR<->RGB swaps of cvtColor + imwrite cancel).  fake [B, T, H, W, 3] in 0..255 -> [B, H, W, 3] uint8."""

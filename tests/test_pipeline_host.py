@@ -187,3 +187,18 @@ def test_landmark_images_match_circle_restatement_everywhere():
             P._draw_disc(a, cx, cy, P._disc_rows(r), value=255)
             ref_circle.circle_filled(b, (cx, cy), r)
             assert np.array_equal(a, b), (r, cx, cy)
+
+
+def test_gif_output_and_video_mux_is_loud_without_its_tools(tmp_path):
+    """sample.py:55-76 / 107-116: GIF through PIL (always available); the mp4 mux needs imageio + ffmpeg like the reference and
+    says so when they are absent instead of writing nothing."""
+    from PIL import Image
+    fr = (np.arange(4 * 8 * 8 * 3) % 251).astype(np.uint8).reshape(4, 8, 8, 3)
+    name = P.save_gif(fr, str(tmp_path / "generated_gif.gif"))
+    im = Image.open(name)
+    assert im.n_frames == 4 and im.size == (8, 8)
+    try:
+        import imageio  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="imageio"):
+            P.make_video(fr, None, str(tmp_path / "out.mp4"))
