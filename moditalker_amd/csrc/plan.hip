@@ -280,6 +280,8 @@ struct Builder {
             a0.gn.inv_n[2] = 1.0 / ((double)(sg.L - sg.b2) * gs);
             a0.gn.inv_n[3] = 1.0 / ((double)sg.L * gs);
         }
+        if ((long)B * a0.Lout >= 2048)             // split-bf16 copy of the weights for the large-token-count kernel k_conv_b3
+            a0.W3 = c->w3_for(a0.W, a0.ntaps * a0.Cmain + a0.Cskip, a0.ldw, &a0.w3_plane);
         account_conv(a0);
         static const bool stamps_env = getenv("MTV_STAMPS") != nullptr;      // diagnostic build only (mtv_debug_stamps)
         if (stamps_env) a0.dbg = reinterpret_cast<unsigned long long*>(c->buf("dbg." + name + "." + std::to_string(mode) + "." + std::to_string(B), 128));
@@ -662,6 +664,7 @@ struct Builder {
 // testing aid: MTV_FORCE_LDS="WM,WN" (or mtv_debug_force_lds) runs every eligible conv of plans built afterwards on the
 // LDS-tiled kernel k_conv_lds<WM, WN>; a conv that turns out not to be eligible at launch falls back (launch_conv)
 static int g_force_wm = -1, g_force_wn = 0;
+static int g_force_b3[2] = {-1, 0};          // MTV_FORCE_B3="MT,NT" (or mtv_debug_force_b3): every eligible conv on k_conv_b3<MT, NT>
 static int g_force_lin[3] = {-1, 0, 0};     // MTV_FORCE_LIN="MT,NT,NWV" (or mtv_debug_force_lin): every eligible 1x1 conv on k_lin<MT, NT, NWV>
 void force_lds_tile(const ConvArgs& a, ConvTile* t) {
     if (g_force_lin[0] == -1) {
@@ -672,6 +675,17 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
         }
     }
     if (g_force_lin[0] > 0 && conv_lin_eligible(a)) { *t = ConvTile{g_force_lin[0], g_force_lin[1], 64, g_force_lin[2], 0}; return; }
+    if (g_force_b3[0] == -1) {
+        g_force_b3[0] = 0;
+        if (const char* e = getenv("MTV_FORCE_B3")) {
+            int x = 0, y = 0;
+            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 2 || x == 4) && (y == 1 || y == 2 || y == 4)) { g_force_b3[0] = x; g_force_b3[1] = y; }
+        }
+    }
+    if (g_force_b3[0] > 0 && conv_b3_eligible(a) && conv_b3_smem_bytes(a, ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0}) <= CONV_B3_MAX_LDS) {
+        *t = ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0};
+        return;
+    }
     if (g_force_wm == -1) {
         g_force_wm = 0;
         if (const char* e = getenv("MTV_FORCE_LDS")) {
@@ -762,7 +776,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     p->tuned = true;
     tune_cache_load(c);
     const char* env = getenv("MTV_AUTOTUNE");
-    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0 || g_force_lin[0] > 0) return MTV_OK;
+    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0 || g_force_lin[0] > 0 || g_force_b3[0] > 0) return MTV_OK;
     static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
     struct Events {             // destroyed on every exit path (HIPCHK returns early)
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -793,12 +807,14 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
             const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
-            const bool shape_ok = tiled_ok || lin_ok ||
+            const bool b3_ok = t.NW == 48 && (t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && t.KS == 1 && t.XM == 0 && conv_b3_eligible(a) &&
+                               conv_b3_smem_bytes(a, t) <= CONV_B3_MAX_LDS;
+            const bool shape_ok = tiled_ok || lin_ok || b3_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
                                    t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1));
-            if (!shape_ok || (!tiled_ok && !lin_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
-                conv_smem_bytes(a, t) > 120 * 1024) {
+            if (!shape_ok || (!tiled_ok && !lin_ok && !b3_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
+                (!b3_ok && conv_smem_bytes(a, t) > 120 * 1024)) {
                 c->tune_cache.erase(it);
                 it = c->tune_cache.end();
             }
@@ -859,6 +875,31 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                     if (mn[1] == 8 && a.N < 256) continue;
                     if ((long)a.B * ((a.Lout + 32 * t.MT - 1) / (32 * t.MT)) * ((a.N + 32 * t.NT - 1) / (32 * t.NT)) < 128) continue;
                     if (conv_smem_bytes(a, t) > 120 * 1024) continue;
+                    float samp[16];
+                    HIPCHK(launch_conv(a, t, s));
+                    for (int w = 0; w < nsamp; ++w) {
+                        HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
+                        HIPCHK(hipEventRecord(e0, s));
+                        HIPCHK(launch_conv(a, t, s));
+                        HIPCHK(hipEventRecord(e1, s));
+                        HIPCHK(hipEventSynchronize(e1));
+                        HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
+                    }
+                    std::sort(samp, samp + nsamp);
+                    if (samp[nsamp / 2] < best_ms) {
+                        best_ms = samp[nsamp / 2];
+                        best = t;
+                    }
+                }
+            }
+            // the split-bf16 LDS kernel (conv_b3.hip) for large token counts
+            if ((long)a.B * a.Lout >= 2048 && conv_b3_eligible(a)) {
+                static const int tb[][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {2, 4}, {4, 4}};
+                for (auto& mn : tb) {
+                    const ConvTile t{mn[0], mn[1], 48, 1, 0};
+                    if (64 * t.NT > a.N && t.NT > 1) continue;
+                    if ((long)a.B * ((a.Lout + 32 * t.MT - 1) / (32 * t.MT)) * ((a.N + 64 * t.NT - 1) / (64 * t.NT)) < 64) continue;
+                    if (conv_b3_smem_bytes(a, t) > CONV_B3_MAX_LDS) continue;
                     float samp[16];
                     HIPCHK(launch_conv(a, t, s));
                     for (int w = 0; w < nsamp; ++w) {
@@ -1126,6 +1167,7 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
         HIPCHK(hipStreamSynchronize(nullptr));
     }
     s.loaded = true;
+    for (auto& kv : c->w3) kv.second.dirty = true;      // (rebuilt before the next run: check_ready)
     return MTV_OK;
 }
 
@@ -1141,6 +1183,14 @@ int check_ready(mtv_ctx* c, int batch) {
             if (!s.loaded) { first = s.key; break; }
         return fail(MTV_ERR_WEIGHT, std::to_string(miss) + " weights not loaded (first: " + first + ")");
     }
+    bool any = false;
+    for (auto& kv : c->w3)
+        if (kv.second.dirty) {
+            HIPCHK(launch_split_w3(kv.first, kv.second.p, kv.second.plane_bytes, 0, kv.second.K, kv.second.ld, nullptr));
+            kv.second.dirty = false;
+            any = true;
+        }
+    if (any) HIPCHK(hipStreamSynchronize(nullptr));
     return MTV_OK;
 }
 
@@ -1447,6 +1497,13 @@ int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up)
 int mtv_debug_attention_b3(int mode) {
     if (mode < -1 || mode > 1) return fail(MTV_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (every eligible launch)");
     g_attn_b3_mode = mode;
+    return MTV_OK;
+}
+
+int mtv_debug_force_b3(int mt, int nt) {
+    if (mt == 0) { g_force_b3[0] = 0; return MTV_OK; }
+    if (!((mt == 2 || mt == 4) && (nt == 1 || nt == 2 || nt == 4))) return fail(MTV_ERR_INVALID, "k_conv_b3 tile must be {2,4} x {1,2,4}");
+    g_force_b3[0] = mt; g_force_b3[1] = nt;
     return MTV_OK;
 }
 

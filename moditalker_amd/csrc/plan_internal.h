@@ -157,6 +157,24 @@ struct mtv_ctx {
     bool accounting = false;
     float* staging = nullptr;
     size_t staging_floats = 0;
+    // split-bf16 copies of conv / GEMM weight matrices (k_conv_b3): W [K][ld] f32 -> three bf16 planes, rebuilt after weight loads
+    struct W3Info { void* p; size_t plane_bytes; int K, ld; bool dirty; };
+    std::map<const float*, W3Info> w3;
+    const void* w3_for(const float* W, int K, int ld, unsigned long long* plane_out) {
+        if (K & 7) return nullptr;
+        auto it = w3.find(W);
+        if (it == w3.end()) {
+            void* p = nullptr;
+            const size_t plane = (size_t)K * ld * 2;
+            if (dmalloc(&p, 3 * plane) != MTV_OK) return nullptr;
+            it = w3.emplace(W, W3Info{p, plane, K, ld, true}).first;
+            // a plan built lazily (first run at a new batch size) comes after check_ready's refresh: split what the weight holds now
+            if (launch_split_w3(W, p, plane, 0, K, ld, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;
+        }
+        if (it->second.K != K || it->second.ld != ld) return nullptr;
+        *plane_out = it->second.plane_bytes;
+        return it->second.p;
+    }
     std::map<std::string, ConvTile> tune_cache;           // conv shape -> measured best tile
     void* flush = nullptr;                                // cache-flush scratch for cold auto-tune timing
     size_t flush_bytes = 0;
@@ -246,6 +264,6 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s);          // measured tile per 
 int finish_split_k(mtv_ctx* c, Plan* p);                   // slab + arrival counters shared by the plan's split-K convs
 int run_ops(mtv_ctx* c, Plan* p, hipStream_t s);
 int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out);
-int check_ready(mtv_ctx* c, int batch);
+int check_ready(mtv_ctx* c, int batch);                     // (also refreshes the split-bf16 weight copies after a weight load)
 int ctx_init_common(mtv_ctx* c);
 void force_lds_tile(const ConvArgs& a, ConvTile* t);    // MTV_FORCE_LDS / MTV_FORCE_LIN testing aids

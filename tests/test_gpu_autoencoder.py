@@ -231,3 +231,26 @@ def test_config4_full_size_through_conditioning_vs_oracle(tmp_path):
     assert float(((fake - fr) / 127.5).abs().max()) <= TOL
     d = np.abs(u8.astype(np.int32) - fr.to(torch.uint8).numpy().astype(np.int32))
     assert u8.shape == (1, T, res, res, 3) and d.max() <= 1 and d.mean() <= 0.01, (int(d.max()), float(d.mean()))
+
+
+def test_autoencoder_on_split_bf16_gemms_vs_reference_golden():
+    """The autoencoder's 16384-token GEMMs forced onto k_conv_b3 (split-bf16 LDS kernel, csrc/conv_b3.hip): decode_from_sample
+    and extract at the shipped 256x256 geometry against the reference's golden outputs, the same 1e-3 bar as the f32 kernels."""
+    from moditalker_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_force_b3(4, 2), "mtv_debug_force_b3")
+    try:
+        g = np.load(os.path.join(GOLDEN, "ae.npz"))
+        seed, res = int(g["full_seed"]), 256
+        ae = _ae(res, seed, 1)
+        r = res // 8
+        lat = filler.uniform_pm1("ae.full.latent", (1, 4, r * r + 2 * 16 * r), seed)
+        frames = ae.decode_from_sample(lat.to(_dev())).cpu()
+        assert float((frames[:, :, ::5, ::5] - torch.from_numpy(g["full_frames_sub5"])).abs().max()) <= TOL
+        vid = filler.uniform_pm1("ae.full.video", (1, 3, 16, res, res), seed)
+        z = ae.extract(vid.to(_dev())).cpu()
+        assert float((z - torch.from_numpy(g["full_extract"])).abs().max()) <= TOL
+        names = [p["name"] for p in ae.profile(1, False, 1)]
+        assert any("gemm" in n for n in names)
+    finally:
+        lib.mtv_debug_force_b3(0, 0)

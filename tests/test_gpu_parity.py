@@ -419,3 +419,36 @@ def test_batched_eight_clip_plan_vs_reference_golden():
     zb = ref_ddpm.ddim_sample(lambda a, b, c, d: ref_unet.unet_forward(sd, BASE_CFG, a, b, c, d, 32, 16), cb, ib, nb, S)
     for k in range(B):
         assert _maxabs(z[k:k + 1], g[f"sample_S{S}"] if k % 2 == 0 else zb) <= SAMPLE_TOL, k
+
+
+@pytest.mark.parametrize("mt,nt", [(4, 2), (2, 2), (2, 1), (2, 4)])
+def test_split_bf16_lds_conv_kernel_vs_reference_golden(mt, nt):
+    """k_conv_b3 (csrc/conv_b3.hip: LDS-staged conv on v_mfma_f32_16x16x32_bf16, activations and weights as three bf16
+    terms, six partial products, f32 accumulation) forced onto every eligible conv of the base UNet: eps vs the reference
+    golden at t = 999 / 0, the 4-step sample, and a ragged 2-clip geometry (partial tiles, rows straddling planes) vs the
+    oracle -- the same bars as the exact-f32 kernels."""
+    from moditalker_amd import _lib
+    from oracle import ref_unet
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_force_b3(mt, nt), "mtv_debug_force_b3")
+    try:
+        g = np.load(os.path.join(GOLDEN, "base.npz"))
+        net = _build(BASE_CFG, 7, max_batch=1)
+        dev = _dev()
+        x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+        for tv in (999, 0):
+            eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
+            assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
+        names = [p["name"] for p in net.diffusion_model.profile_forward(1, 1, dev)]
+        assert sum(f"t{mt},{nt},48,1]" in n for n in names) >= 25, "the split-bf16 kernel was not selected"      # (the level-0 convs: rows >= 2048)
+        noise = [z.to(dev) for z in filler.noise_list(4, (1, 4, 2048), seed=7, tag="base.S4")]
+        dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=4, w=0.0).to(dev)
+        assert _maxabs(dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=noise), g["sample_S4"]) <= SAMPLE_TOL
+        cfg = dict(BASE_CFG, image_size=24)            # 24x24 | 8x24 | 8x24 planes, two clips: every level has >= 2048 / 4^l ... rows; ragged tiles
+        net2 = _build(cfg, 21, frames=8, max_batch=4)
+        x, cond, ic = filler.synthetic_inputs(4, 24, 8, seed=5, tag="b3")
+        t = torch.tensor([700, 3, 999, 250])
+        ref = ref_unet.unet_forward({k: v.cpu() for k, v in net2.state_dict().items()}, cfg, x, cond, ic, t, 24, 8)
+        assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
+    finally:
+        lib.mtv_debug_force_b3(0, 0)
