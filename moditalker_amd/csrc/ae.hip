@@ -322,7 +322,7 @@ struct AeBuilder {
         a.res = res;
         a.gather = gather;
         a.stat_cstride = 0;
-        if ((long)a.B * rows >= 2048) a.W3 = c->w3_for(W, K, ld, &a.w3_plane);      // split-bf16 weight copy for k_conv_b3
+        if (x3_wanted((long)a.B * rows)) a.W3 = c->w3_for(W, K, ld, &a.w3_plane);      // split-bf16 weight copy for k_conv_x3
         auto op = std::make_shared<ConvOp>();
         op->a = a;
         op->t = conv_pick_tile(a.B, rows, N, K / 16, K, false);

@@ -1225,7 +1225,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
 
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
     if (t.NW == 64) return lin_smem_bytes(a);
-    if (t.NW == 48) return conv_b3_smem_bytes(a, t);
+    if (t.NW == 48) return conv_x3_smem_bytes(a, t);
     if (t.NW == 32) return lds_bytes_tiled(t.MT, t.NT, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
     return lds_bytes(t.MT, t.NT, t.NW, t.KS, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
 }
@@ -1302,7 +1302,7 @@ hipError_t conv_init_attrs() {
                            reinterpret_cast<const void*>(&k_conv_lds<2, 8>), reinterpret_cast<const void*>(&k_conv_lds<4, 8>)};
     for (const void* f : tiled)
         if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
-    return conv_b3_init_attrs();
+    return conv_x3_init_attrs();
 }
 
 hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
@@ -1320,8 +1320,8 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
         a.xmap = 0;            // no padding blocks: every block of the grid takes part in the step hand-over
     }
     hipError_t e = hipErrorInvalidValue;
-    if (t.NW == 48) {            // split-bf16 LDS kernel (conv_b3.hip)
-        if (conv_b3_eligible(a)) return launch_conv_b3(a, t, s);
+    if (t.NW == 48) {            // split-bf16 kernels for large token counts (conv_x3.hip: elementwise pass + gathering GEMM)
+        if (conv_x3_eligible(a) && a.x3) return launch_conv_x3(a, t, s);
         t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);
         t.KS = 1;
         a.KS = 1;

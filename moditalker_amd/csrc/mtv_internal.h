@@ -77,8 +77,9 @@ struct ConvArgs {
     int B;
     const float* W;          // rows [ntaps*Cmain + Cskip][ldw], columns = output channels
     const float* Wnk;        // 1x1 convs on identity rows only: the same weight as stored in the checkpoint, [N][Cmain] (k_lin, lin.hip)
-    const void* W3;          // the same matrix as three bf16 planes [3][K/8][ldw][8] with W = W0 + W1 + W2 (k_conv_b3, conv_b3.hip) or nullptr
+    const void* W3;          // the same matrix as three bf16 planes [3][K/8][ldw][8] with W = W0 + W1 + W2 (k_conv_x3, conv_x3.hip) or nullptr
     unsigned long long w3_plane;   // bytes between the planes
+    void* x3;                // scratch for this conv's split activations (k_x3_prep -> k_conv_x3, conv_x3.hip) or nullptr
     int ldw;
     int N;
     const float* bias;       // [N]
@@ -258,12 +259,14 @@ __device__ __forceinline__ float ddim_update_elem(const DdimStep& st, float x, f
 struct ConvTile { int MT, NT, NW, KS, XM; };   // XM: workgroup->tile mapping (0 rows fastest, 1 weight slice per XCD)
                                                // NW == 32: the LDS-tiled kernel k_conv_lds<WM = MT, WN = NT> (KS = 1, XM = 0)
                                                // NW == 64: the lean 1x1 kernel k_lin<MT, NT, NWV = KS> (lin.hip; XM = 0)
-                                               // NW == 48: the split-bf16 LDS kernel k_conv_b3<MT, NT> (conv_b3.hip; KS = 1, XM = 0)
-bool conv_b3_eligible(const ConvArgs& a);
-size_t conv_b3_smem_bytes(const ConvArgs& a, ConvTile t);
-hipError_t launch_conv_b3(const ConvArgs& a, ConvTile t, hipStream_t s);
-constexpr size_t CONV_B3_MAX_LDS = 160 * 1024 - 4096;   // dynamic LDS a k_conv_b3 launch may ask for (160 KB minus its static arrays)
-hipError_t conv_b3_init_attrs();
+                                               // NW == 48: the split-bf16 kernels k_x3_prep + k_conv_x3<MT, NT> (conv_x3.hip; KS = 1, XM = 0)
+constexpr size_t CONV_X3_MAX_LDS = 160 * 1024;          // k_conv_x3 has no static LDS: the whole 160 KB
+bool conv_x3_eligible(const ConvArgs& a);
+bool x3_tile_exists(int MT, int NT);
+size_t conv_x3_scratch_bytes(int B, int Lsrc, int Cmain, int Lskip, int Cskip);
+size_t conv_x3_smem_bytes(const ConvArgs& a, ConvTile t);
+hipError_t conv_x3_init_attrs();
+hipError_t launch_conv_x3(const ConvArgs& a, ConvTile t, hipStream_t s);
 hipError_t launch_split_w3(const float* W, void* W3, size_t plane_bytes, int row0, int rows, int ldw, hipStream_t s);
 bool conv_lin_eligible(const ConvArgs& a);
 size_t lin_smem_bytes(const ConvArgs& a);

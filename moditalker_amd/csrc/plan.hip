@@ -280,7 +280,7 @@ struct Builder {
             a0.gn.inv_n[2] = 1.0 / ((double)(sg.L - sg.b2) * gs);
             a0.gn.inv_n[3] = 1.0 / ((double)sg.L * gs);
         }
-        if ((long)B * a0.Lout >= 2048)             // split-bf16 copy of the weights for the large-token-count kernel k_conv_b3
+        if (x3_wanted((long)B * a0.Lout))          // split-bf16 copy of the weights for the large-token-count kernel k_conv_x3
             a0.W3 = c->w3_for(a0.W, a0.ntaps * a0.Cmain + a0.Cskip, a0.ldw, &a0.w3_plane);
         account_conv(a0);
         static const bool stamps_env = getenv("MTV_STAMPS") != nullptr;      // diagnostic build only (mtv_debug_stamps)
@@ -664,8 +664,23 @@ struct Builder {
 // testing aid: MTV_FORCE_LDS="WM,WN" (or mtv_debug_force_lds) runs every eligible conv of plans built afterwards on the
 // LDS-tiled kernel k_conv_lds<WM, WN>; a conv that turns out not to be eligible at launch falls back (launch_conv)
 static int g_force_wm = -1, g_force_wn = 0;
-static int g_force_b3[2] = {-1, 0};          // MTV_FORCE_B3="MT,NT" (or mtv_debug_force_b3): every eligible conv on k_conv_b3<MT, NT>
+static int g_force_b3[2] = {-1, 0};          // MTV_FORCE_B3="MT,NT" (or mtv_debug_force_b3): every eligible conv on the split-bf16 kernel k_conv_x3<MT, NT>
 static int g_force_lin[3] = {-1, 0, 0};     // MTV_FORCE_LIN="MT,NT,NWV" (or mtv_debug_force_lin): every eligible 1x1 conv on k_lin<MT, NT, NWV>
+static void parse_force_b3() {
+    if (g_force_b3[0] != -1) return;
+    g_force_b3[0] = 0;
+    if (const char* e = getenv("MTV_FORCE_B3")) {
+        int x = 0, y = 0;
+        if (sscanf(e, "%d,%d", &x, &y) == 2 && x3_tile_exists(x, y)) { g_force_b3[0] = x; g_force_b3[1] = y; }
+    }
+}
+// Convs of at least X3_MIN_ROWS tokens (all clips together) get a split-bf16 weight copy + activation scratch and are offered to
+// the tuner on k_conv_x3; below that the elementwise pass and the few 128-row tiles cannot pay (profiles/r03_conv_x3_bench.txt).
+// A forced tile (tests) lifts the bound.
+bool x3_wanted(long rows) {
+    parse_force_b3();
+    return rows >= X3_MIN_ROWS || g_force_b3[0] > 0;
+}
 void force_lds_tile(const ConvArgs& a, ConvTile* t) {
     if (g_force_lin[0] == -1) {
         g_force_lin[0] = 0;
@@ -675,14 +690,8 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
         }
     }
     if (g_force_lin[0] > 0 && conv_lin_eligible(a)) { *t = ConvTile{g_force_lin[0], g_force_lin[1], 64, g_force_lin[2], 0}; return; }
-    if (g_force_b3[0] == -1) {
-        g_force_b3[0] = 0;
-        if (const char* e = getenv("MTV_FORCE_B3")) {
-            int x = 0, y = 0;
-            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 2 || x == 4) && (y == 1 || y == 2 || y == 4)) { g_force_b3[0] = x; g_force_b3[1] = y; }
-        }
-    }
-    if (g_force_b3[0] > 0 && conv_b3_eligible(a) && conv_b3_smem_bytes(a, ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0}) <= CONV_B3_MAX_LDS) {
+    parse_force_b3();
+    if (g_force_b3[0] > 0 && conv_x3_eligible(a) && conv_x3_smem_bytes(a, ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0}) <= CONV_X3_MAX_LDS) {
         *t = ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0};
         return;
     }
@@ -718,6 +727,16 @@ int finish_split_k(mtv_ctx* c, Plan* plan) {
     // what the tuner may use = what is really allocated for THIS plan (autotune validates K slices against it)
     plan->slab_floats = c->buf_floats["slab.B" + tag];
     for (auto& op : plan->convs) op->a.slab = slab;
+    // ... and one scratch for the split activations of the convs that may run on the split-bf16 kernels (those with a W3 copy)
+    size_t x3need = 0;
+    for (auto& op : plan->convs)
+        if (op->a.W3) x3need = std::max(x3need, conv_x3_scratch_bytes(B, op->a.Lsrc, op->a.Cmain, op->a.Lskip, op->a.Cskip));
+    if (x3need) {
+        float* x3 = c->buf("x3.B" + tag, (x3need + 3) / 4);
+        if (!x3) return fail(MTV_ERR_HIP, "split-activation scratch allocation failed: " + std::string(mtv_last_error()));
+        for (auto& op : plan->convs)
+            if (op->a.W3) op->a.x3 = x3;
+    }
     size_t nt = 0;
     for (auto& op : plan->convs) nt += (size_t)B * ((op->a.Lout + 15) / 16) * ((op->a.N + 15) / 16);
     int* tk = (int*)c->buf("tickets.B" + tag, nt);
@@ -807,8 +826,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
             const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
-            const bool b3_ok = t.NW == 48 && (t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && t.KS == 1 && t.XM == 0 && conv_b3_eligible(a) &&
-                               conv_b3_smem_bytes(a, t) <= CONV_B3_MAX_LDS;
+            const bool b3_ok = t.NW == 48 && x3_tile_exists(t.MT, t.NT) && t.KS == 1 && t.XM == 0 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
             const bool shape_ok = tiled_ok || lin_ok || b3_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
@@ -892,14 +910,14 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                     }
                 }
             }
-            // the split-bf16 LDS kernel (conv_b3.hip) for large token counts
-            if ((long)a.B * a.Lout >= 2048 && conv_b3_eligible(a)) {
-                static const int tb[][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {2, 4}, {4, 4}};
+            // the split-bf16 kernels (conv_x3.hip) for large token counts: the timed launch is the elementwise pass + the GEMM
+            if ((long)a.B * a.Lout >= X3_MIN_ROWS && conv_x3_eligible(a) && a.x3) {
+                static const int tb[][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {8, 2}, {8, 1}, {4, 4}};
                 for (auto& mn : tb) {
                     const ConvTile t{mn[0], mn[1], 48, 1, 0};
                     if (64 * t.NT > a.N && t.NT > 1) continue;
                     if ((long)a.B * ((a.Lout + 32 * t.MT - 1) / (32 * t.MT)) * ((a.N + 64 * t.NT - 1) / (64 * t.NT)) < 64) continue;
-                    if (conv_b3_smem_bytes(a, t) > CONV_B3_MAX_LDS) continue;
+                    if (conv_x3_smem_bytes(a, t) > CONV_X3_MAX_LDS) continue;
                     float samp[16];
                     HIPCHK(launch_conv(a, t, s));
                     for (int w = 0; w < nsamp; ++w) {
@@ -1502,7 +1520,7 @@ int mtv_debug_attention_b3(int mode) {
 
 int mtv_debug_force_b3(int mt, int nt) {
     if (mt == 0) { g_force_b3[0] = 0; return MTV_OK; }
-    if (!((mt == 2 || mt == 4) && (nt == 1 || nt == 2 || nt == 4))) return fail(MTV_ERR_INVALID, "k_conv_b3 tile must be {2,4} x {1,2,4}");
+    if (!x3_tile_exists(mt, nt)) return fail(MTV_ERR_INVALID, "no k_conv_x3<MT, NT> of that shape (4,2 8,2 4,4 2,2 4,1 2,1 8,1)");
     g_force_b3[0] = mt; g_force_b3[1] = nt;
     return MTV_OK;
 }

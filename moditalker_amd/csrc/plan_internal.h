@@ -157,7 +157,7 @@ struct mtv_ctx {
     bool accounting = false;
     float* staging = nullptr;
     size_t staging_floats = 0;
-    // split-bf16 copies of conv / GEMM weight matrices (k_conv_b3): W [K][ld] f32 -> three bf16 planes, rebuilt after weight loads
+    // split-bf16 copies of conv / GEMM weight matrices (k_conv_x3): W [K][ld] f32 -> three bf16 planes, rebuilt after weight loads
     struct W3Info { void* p; size_t plane_bytes; int K, ld; bool dirty; };
     std::map<const float*, W3Info> w3;
     const void* w3_for(const float* W, int K, int ld, unsigned long long* plane_out) {
@@ -264,6 +264,8 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s);          // measured tile per 
 int finish_split_k(mtv_ctx* c, Plan* p);                   // slab + arrival counters shared by the plan's split-K convs
 int run_ops(mtv_ctx* c, Plan* p, hipStream_t s);
 int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out);
+constexpr long X3_MIN_ROWS = 4096;
+bool x3_wanted(long rows);                                  // plan.hip: offer this conv to the split-bf16 kernels?
 int check_ready(mtv_ctx* c, int batch);                     // (also refreshes the split-bf16 weight copies after a weight load)
 int ctx_init_common(mtv_ctx* c);
 void force_lds_tile(const ConvArgs& a, ConvTile* t);    // MTV_FORCE_LDS / MTV_FORCE_LIN testing aids

@@ -234,7 +234,7 @@ def test_config4_full_size_through_conditioning_vs_oracle(tmp_path):
 
 
 def test_autoencoder_on_split_bf16_gemms_vs_reference_golden():
-    """The autoencoder's 16384-token GEMMs forced onto k_conv_b3 (split-bf16 LDS kernel, csrc/conv_b3.hip): decode_from_sample
+    """The autoencoder's 16384-token GEMMs forced onto k_x3_prep + k_conv_x3 (split-bf16 kernels, csrc/conv_x3.hip): decode_from_sample
     and extract at the shipped 256x256 geometry against the reference's golden outputs, the same 1e-3 bar as the f32 kernels."""
     from moditalker_amd import _lib
     lib = _lib.load()

@@ -421,12 +421,13 @@ def test_batched_eight_clip_plan_vs_reference_golden():
         assert _maxabs(z[k:k + 1], g[f"sample_S{S}"] if k % 2 == 0 else zb) <= SAMPLE_TOL, k
 
 
-@pytest.mark.parametrize("mt,nt", [(4, 2), (2, 2), (2, 1), (2, 4)])
+@pytest.mark.parametrize("mt,nt", [(4, 2), (2, 2), (2, 1), (8, 2), (4, 4), (8, 1), (4, 1)])
 def test_split_bf16_lds_conv_kernel_vs_reference_golden(mt, nt):
-    """k_conv_b3 (csrc/conv_b3.hip: LDS-staged conv on v_mfma_f32_16x16x32_bf16, activations and weights as three bf16
-    terms, six partial products, f32 accumulation) forced onto every eligible conv of the base UNet: eps vs the reference
-    golden at t = 999 / 0, the 4-step sample, and a ragged 2-clip geometry (partial tiles, rows straddling planes) vs the
-    oracle -- the same bars as the exact-f32 kernels."""
+    """k_x3_prep + k_conv_x3 (csrc/conv_x3.hip: GroupNorm / SiLU / three-term bf16 split in one elementwise pass, then a
+    gathering GEMM on v_mfma_f32_16x16x32_bf16 with both operands by LDS-DMA, six partial products, f32 accumulation) forced onto
+    every eligible conv of the base UNet: eps vs the reference golden at t = 999 / 0, the 4-step sample, and a ragged 2-clip
+    geometry (partial tiles, rows straddling planes, column tiles wider than N) vs the oracle -- the same bars as the exact-f32
+    kernels."""
     from moditalker_amd import _lib
     from oracle import ref_unet
     lib = _lib.load()
