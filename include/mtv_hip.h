@@ -141,9 +141,10 @@ int mtv_debug_stamps(mtv_ctx* ctx, int batch, const char* path, void* stream);
 /* Testing aid: plans built after this call run every eligible convolution on the LDS-tiled kernel k_conv_lds<wm, wn>
  * (wave tile 16 wm x 16 wn, workgroup 2 x 2 waves) instead of the tuned choice; wm = 0 switches it off again. */
 int mtv_debug_force_lds(int wm, int wn);
-/* Testing aid: plans built after this call run every eligible convolution / GEMM of >= 2048 rows on the split-bf16 LDS
- * kernel k_conv_b3<mt, nt> (workgroup tile 32 mt x 64 nt, csrc/conv_b3.hip) instead of the tuned choice; mt = 0: off. */
-int mtv_debug_force_b3(int mt, int nt);
+/* Testing aid: plans built after this call run every eligible convolution / GEMM (any row count) on the split-bf16 kernels
+ * k_x3_prep + k_conv_x3<mt, nt> (workgroup tile 32 mt x 64 nt, csrc/conv_x3.hip) with `ks` K slices per tile (1, 2, 4, 8;
+ * convs with fewer than 6 ks 32-channel chunks keep one slice) instead of the tuned choice; mt = 0: off. */
+int mtv_debug_force_b3(int mt, int nt, int ks);
 /* Testing aid: plans built after this call run every eligible 1x1 convolution (the attention blocks' qkv / proj_out,
  * unet.py:234,253) on the lean kernel k_lin<mt, nt, nwv> (wave tile 16 mt x 16 nt, nwv waves side by side along the
  * output channels, whole K per wave; csrc/lin.hip) instead of the tuned choice; mt = 0 switches it off again. */

@@ -233,7 +233,12 @@ struct X3Args {
     unsigned stat_cstride;
     int tiles_per_b, tiles_n;
     float inv_tiles_per_b, inv_tiles_n;
-    int nblk, xcd_q, xcd_r;                // workgroups; nblk / 8 and nblk % 8 (XCD-contiguous block order)
+    int nblk, xcd_q, xcd_r;                // workgroups (all K slices); their number / 8 and % 8 (XCD-contiguous block order)
+    int ntile;                             // output tiles = nblk / KS
+    int KS, cps_q, cps_r;                  // cross-workgroup split-K: slices; chunks per slice nch / KS and nch % KS
+    float inv_ntile;
+    float* slab;                           // [KS][B][Lout][N] partial tiles
+    int* tickets;                          // [ntile] arrival counters (zero between launches)
     unsigned long long* dbg;               // tools/ubench/x3_bench (-DX3_STAMP): phase timestamps; unused otherwise
 };
 
@@ -283,8 +288,12 @@ __global__ __launch_bounds__(512) void k_conv_x3(const X3Args a) {
         const int x = blk & 7, j = blk >> 3;
         blk = (x < a.xcd_r ? x * (a.xcd_q + 1) : a.xcd_r * (a.xcd_q + 1) + (x - a.xcd_r) * a.xcd_q) + j;
     }
+    const int ks = __builtin_amdgcn_readfirstlane(a.KS > 1 ? x3_div(blk, a.ntile, a.inv_ntile) : 0);      // K slice (slowest)
+    blk -= ks * a.ntile;
+    const int tile_id = blk;
     const int bx = __builtin_amdgcn_readfirstlane(x3_div(blk, a.tiles_n, a.inv_tiles_n));      // column tiles fastest
     const int by = blk - bx * a.tiles_n;
+    const int c_begin = ks * a.cps_q + min(ks, a.cps_r), c_end = c_begin + a.cps_q + (ks < a.cps_r ? 1 : 0);     // this slice's chunks
     const int b = __builtin_amdgcn_readfirstlane(x3_div(bx, a.tiles_per_b, a.inv_tiles_per_b));
     const int tok0 = (bx - b * a.tiles_per_b) * BM;
     const int n0 = by * BN;
@@ -378,15 +387,28 @@ __global__ __launch_bounds__(512) void k_conv_x3(const X3Args a) {
                 pc_v[k] = (unsigned)(skipc ? b * a.Lskip + v : v) * 16u;
             }
     };
-    set_bases(false);
-    tap_rows(0, false);
-    int x_ch = 0, x_tap = 0, x_w = 0;
-    size_t chA = 0, chW = 0;
-    size_t strideA = (size_t)a.rowsM * 64u;
     const size_t strideW = (size_t)a.ldw * 64u;
+    int x_ch = c_begin, x_tap, x_w;
+    size_t chA, chW = (size_t)c_begin * strideW, strideA;
+    if (c_begin < a.nmainch) {
+        x_tap = c_begin / a.cpt;
+        x_w = c_begin - x_tap * a.cpt;
+        strideA = (size_t)a.rowsM * 64u;
+        chA = (size_t)x_w * strideA;
+        set_bases(false);
+        tap_rows(x_tap, false);
+    } else {                                  // (a slice that starts inside the skip part)
+        x_tap = ntaps;
+        x_w = 0;
+        strideA = (size_t)a.rowsS * 64u;
+        chA = (size_t)(c_begin - a.nmainch) * strideA;
+        set_bases(false);
+        set_bases(true);
+        tap_rows(ntaps, true);
+    }
     auto issue = [&](int st) {
         lchar* const sb = lds0 + tab + st * SH::STAGE;
-        if (x_ch < a.nch) {
+        if (x_ch < c_end) {
 #pragma unroll
             for (int k = 0; k < P; ++k) {
                 const char* g = pc_base[k] + (pc_isw[k] ? chW : chA);
@@ -401,7 +423,7 @@ __global__ __launch_bounds__(512) void k_conv_x3(const X3Args a) {
             if (++x_w == a.cpt) {          // next tap (or the skip part, whose chunks simply keep advancing)
                 x_w = 0;
                 ++x_tap;
-                if (x_ch < a.nch) {
+                if (x_ch < c_end) {
                     const bool skipc = x_ch >= a.nmainch;
                     if (skipc) {
                         if (x_ch == a.nmainch) {
@@ -478,7 +500,7 @@ __global__ __launch_bounds__(512) void k_conv_x3(const X3Args a) {
         __builtin_amdgcn_s_waitcnt(x3_waitcnt_vm_lgkm0((D - 1) * P));
         __builtin_amdgcn_s_barrier();
         int st_c = 0, st_i = D;          // stage of chunk c; stage to refill (= stage of chunk c - 1)
-        const int nch = a.nch;
+        const int nch = c_end - c_begin;
         if (wave < 4) {
             for (int c = 0; c < nch; ++c) {
                 XSTAMP(c, 0);
@@ -519,11 +541,74 @@ __global__ __launch_bounds__(512) void k_conv_x3(const X3Args a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue from the accumulators: lane (i, q) of wave (wm, wn) holds, for row 4q + r of row block mt, the NT
-    // consecutive output channels n0 + 16 NT wn + NT i ..
+    // ---- lane (i, q) of wave (wm, wn) holds, for row 4q + r of row block mt, the NT consecutive output channels
+    // n0 + 16 NT wn + NT i ..
     const bool fast = a.nstat > 0;
     constexpr int QPR = BN / 4;
     const int colw = n0 + wn * 16 * NT + NT * i;
+    if (a.KS > 1) {
+        // Cross-workgroup split-K completed inside the launch, the protocol of k_conv (conv.hip): every slice parks its partial tile
+        // in the slab with write-through (agent-scope) stores and drains them, one lane takes a ticket, the slice that draws the
+        // last one re-reads ALL slices in slice order (the result does not depend on who finishes last) and runs the epilogue.
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        const size_t sstride = (size_t)a.B * a.Lout * a.N;
+        if (colw < a.N) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tok = tok0 + wm * 16 * MT + 16 * mt + 4 * q + r;
+                    if (tok >= a.Lout) continue;
+                    float* dp = a.slab + (size_t)ks * sstride + ((size_t)b * a.Lout + tok) * a.N + colw;
+                    if constexpr (NT == 1) {
+                        __hip_atomic_store((gu32*)(unsigned long long)dp, __float_as_uint(acc[mt][0][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < NT / 2; ++h)
+                            __hip_atomic_store((gu64*)(unsigned long long)dp + h, ((unsigned long long)__float_as_uint(acc[mt][2 * h + 1][r]) << 32) | __float_as_uint(acc[mt][2 * h][r]),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* s_last = reinterpret_cast<int*>(x3_smem + dump_off);          // (the padding pieces have landed: the dump is free)
+        if (tid == 0) {
+            const bool last = __hip_atomic_fetch_add(a.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.KS - 1;
+            if (last) __hip_atomic_store(a.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // self-cleaning for the next launch
+            s_last[0] = last ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last[0]) return;
+        if (colw < a.N) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tok = tok0 + wm * 16 * MT + 16 * mt + 4 * q + r;
+                    if (tok >= a.Lout) continue;
+                    const float* sp = a.slab + ((size_t)b * a.Lout + tok) * a.N + colw;
+                    float v[NT];
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) v[nb] = 0.f;
+                    for (int s2 = 0; s2 < a.KS; ++s2) {
+                        if constexpr (NT == 1) {
+                            v[0] += __uint_as_float(__hip_atomic_load((gu32*)(unsigned long long)(sp + (size_t)s2 * sstride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        } else {
+#pragma unroll
+                            for (int h = 0; h < NT / 2; ++h) {
+                                const unsigned long long t = __hip_atomic_load((gu64*)(unsigned long long)(sp + (size_t)s2 * sstride) + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                v[2 * h] += __uint_as_float((unsigned)t);
+                                v[2 * h + 1] += __uint_as_float((unsigned)(t >> 32));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) acc[mt][nb][r] = v[nb];
+                }
+        }
+    }
     if (colw < a.N) {
         float bias[NT];
 #pragma unroll
@@ -669,7 +754,7 @@ static hipError_t launch_x3_prep(const ConvArgs& a, hipStream_t s) {
 }
 
 template <int MT, int NT>
-static hipError_t launch_x3_t(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_x3_t(const ConvArgs& a, int KSv, hipStream_t s) {
     constexpr int BM = 32 * MT, BN = 64 * NT;
     X3Args x{};
     x.A3 = reinterpret_cast<const char*>(a.x3);
@@ -689,8 +774,12 @@ static hipError_t launch_x3_t(const ConvArgs& a, hipStream_t s) {
     x.res = a.res; x.out = a.out; x.seg_out = a.seg_out;
     x.stat[0] = a.stat[0]; x.stat[1] = a.stat[1]; x.nstat = a.nstat; x.stat_cstride = a.stat_cstride;
     const int tiles = (a.Lout + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    const long nblk = (long)a.B * tiles * tiles_n;
-    if (nblk >= (1L << 21)) return hipErrorInvalidValue;
+    const int KS = KSv < 1 ? 1 : KSv;
+    const long ntile = (long)a.B * tiles * tiles_n, nblk = ntile * KS;
+    if (nblk >= (1L << 21) || KS > x.nch || (KS > 1 && (!a.slab || !a.tickets))) return hipErrorInvalidValue;
+    x.ntile = (int)ntile; x.inv_ntile = 1.0f / (float)ntile;
+    x.KS = KS; x.cps_q = x.nch / KS; x.cps_r = x.nch % KS;
+    x.slab = a.slab; x.tickets = a.tickets;
     x.tiles_per_b = tiles; x.tiles_n = tiles_n;
     x.inv_tiles_per_b = 1.0f / (float)tiles; x.inv_tiles_n = 1.0f / (float)tiles_n;
     x.nblk = (int)nblk; x.xcd_q = (int)(nblk / 8); x.xcd_r = (int)(nblk % 8);
@@ -708,12 +797,12 @@ hipError_t conv_x3_init_attrs() {
     return hipSuccess;
 }
 
-// tiles are encoded as ConvTile{MT, NT, NW = 96, KS = 1, XM = 0}; the launch is the elementwise pass + the GEMM
+// tiles are encoded as ConvTile{MT, NT, NW = 48, KS, XM = 0}; the launch is the elementwise pass + the GEMM (KS K slices per tile)
 hipError_t launch_conv_x3(const ConvArgs& a, ConvTile t, hipStream_t s) {
     if (!conv_x3_eligible(a) || !a.x3) return hipErrorInvalidValue;
     hipError_t e = launch_x3_prep(a, s);
     if (e != hipSuccess) return e;
-#define X3_L(M, N_) if (t.MT == M && t.NT == N_) return launch_x3_t<M, N_>(a, s);
+#define X3_L(M, N_) if (t.MT == M && t.NT == N_) return launch_x3_t<M, N_>(a, t.KS, s);
     X3_TILES(X3_L)
 #undef X3_L
     return hipErrorInvalidValue;

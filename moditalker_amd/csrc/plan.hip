@@ -664,14 +664,15 @@ struct Builder {
 // testing aid: MTV_FORCE_LDS="WM,WN" (or mtv_debug_force_lds) runs every eligible conv of plans built afterwards on the
 // LDS-tiled kernel k_conv_lds<WM, WN>; a conv that turns out not to be eligible at launch falls back (launch_conv)
 static int g_force_wm = -1, g_force_wn = 0;
-static int g_force_b3[2] = {-1, 0};          // MTV_FORCE_B3="MT,NT" (or mtv_debug_force_b3): every eligible conv on the split-bf16 kernel k_conv_x3<MT, NT>
+static int g_force_b3[3] = {-1, 0, 1};       // MTV_FORCE_B3="MT,NT[,KS]" (or mtv_debug_force_b3): every eligible conv on the split-bf16 kernel k_conv_x3<MT, NT>
 static int g_force_lin[3] = {-1, 0, 0};     // MTV_FORCE_LIN="MT,NT,NWV" (or mtv_debug_force_lin): every eligible 1x1 conv on k_lin<MT, NT, NWV>
 static void parse_force_b3() {
     if (g_force_b3[0] != -1) return;
     g_force_b3[0] = 0;
     if (const char* e = getenv("MTV_FORCE_B3")) {
-        int x = 0, y = 0;
-        if (sscanf(e, "%d,%d", &x, &y) == 2 && x3_tile_exists(x, y)) { g_force_b3[0] = x; g_force_b3[1] = y; }
+        int x = 0, y = 0, z = 1;
+        const int n = sscanf(e, "%d,%d,%d", &x, &y, &z);
+        if (n >= 2 && x3_tile_exists(x, y) && (z == 1 || z == 2 || z == 4 || z == 8)) { g_force_b3[0] = x; g_force_b3[1] = y; g_force_b3[2] = z; }
     }
 }
 // Convs of at least X3_MIN_ROWS tokens (all clips together) get a split-bf16 weight copy + activation scratch and are offered to
@@ -692,7 +693,8 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
     if (g_force_lin[0] > 0 && conv_lin_eligible(a)) { *t = ConvTile{g_force_lin[0], g_force_lin[1], 64, g_force_lin[2], 0}; return; }
     parse_force_b3();
     if (g_force_b3[0] > 0 && conv_x3_eligible(a) && conv_x3_smem_bytes(a, ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0}) <= CONV_X3_MAX_LDS) {
-        *t = ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0};
+        const int nch32 = a.ntaps * (a.Cmain / 32) + a.Cskip / 32;
+        *t = ConvTile{g_force_b3[0], g_force_b3[1], 48, nch32 >= 6 * g_force_b3[2] ? g_force_b3[2] : 1, 0};     // (K slices of at least 6 chunks)
         return;
     }
     if (g_force_wm == -1) {
@@ -826,7 +828,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
             const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
-            const bool b3_ok = t.NW == 48 && x3_tile_exists(t.MT, t.NT) && t.KS == 1 && t.XM == 0 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
+            const bool b3_ok = t.NW == 48 && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
             const bool shape_ok = tiled_ok || lin_ok || b3_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
@@ -913,27 +915,32 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             // the split-bf16 kernels (conv_x3.hip) for large token counts: the timed launch is the elementwise pass + the GEMM
             if ((long)a.B * a.Lout >= X3_MIN_ROWS && conv_x3_eligible(a) && a.x3) {
                 static const int tb[][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {8, 2}, {8, 1}, {4, 4}};
-                for (auto& mn : tb) {
-                    const ConvTile t{mn[0], mn[1], 48, 1, 0};
-                    if (64 * t.NT > a.N && t.NT > 1) continue;
-                    if ((long)a.B * ((a.Lout + 32 * t.MT - 1) / (32 * t.MT)) * ((a.N + 64 * t.NT - 1) / (64 * t.NT)) < 64) continue;
-                    if (conv_x3_smem_bytes(a, t) > CONV_X3_MAX_LDS) continue;
-                    float samp[16];
-                    HIPCHK(launch_conv(a, t, s));
-                    for (int w = 0; w < nsamp; ++w) {
-                        HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
-                        HIPCHK(hipEventRecord(e0, s));
+                const int nch32 = a.ntaps * (a.Cmain / 32) + a.Cskip / 32;
+                for (auto& mn : tb)
+                    for (int KS = 1; KS <= 8; KS *= 2) {
+                        const ConvTile t{mn[0], mn[1], 48, KS, 0};
+                        if (64 * t.NT > a.N && t.NT > 1) continue;
+                        const long ntile = (long)a.B * ((a.Lout + 32 * t.MT - 1) / (32 * t.MT)) * ((a.N + 64 * t.NT - 1) / (64 * t.NT));
+                        if (ntile * KS < 64) continue;
+                        // K slices only while the tiles alone leave CUs idle, and never fewer than 6 chunks per slice
+                        if (KS > 1 && (ntile * (KS / 2) >= 256 || nch32 / KS < 6 || (size_t)KS * a.B * a.Lout * a.N > slab_cap)) continue;
+                        if (conv_x3_smem_bytes(a, t) > CONV_X3_MAX_LDS) continue;
+                        float samp[16];
                         HIPCHK(launch_conv(a, t, s));
-                        HIPCHK(hipEventRecord(e1, s));
-                        HIPCHK(hipEventSynchronize(e1));
-                        HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
+                        for (int w = 0; w < nsamp; ++w) {
+                            HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
+                            HIPCHK(hipEventRecord(e0, s));
+                            HIPCHK(launch_conv(a, t, s));
+                            HIPCHK(hipEventRecord(e1, s));
+                            HIPCHK(hipEventSynchronize(e1));
+                            HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
+                        }
+                        std::sort(samp, samp + nsamp);
+                        if (samp[nsamp / 2] < best_ms) {
+                            best_ms = samp[nsamp / 2];
+                            best = t;
+                        }
                     }
-                    std::sort(samp, samp + nsamp);
-                    if (samp[nsamp / 2] < best_ms) {
-                        best_ms = samp[nsamp / 2];
-                        best = t;
-                    }
-                }
             }
             // the lean 1x1 kernel (lin.hip): wave tile 16 MT x 16 NT, NWV waves side by side along N, whole K per wave
             if (conv_lin_eligible(a)) {
@@ -1518,10 +1525,11 @@ int mtv_debug_attention_b3(int mode) {
     return MTV_OK;
 }
 
-int mtv_debug_force_b3(int mt, int nt) {
+int mtv_debug_force_b3(int mt, int nt, int ks) {
     if (mt == 0) { g_force_b3[0] = 0; return MTV_OK; }
+    if (!(ks == 1 || ks == 2 || ks == 4 || ks == 8)) return fail(MTV_ERR_INVALID, "K slices must be 1, 2, 4 or 8");
     if (!x3_tile_exists(mt, nt)) return fail(MTV_ERR_INVALID, "no k_conv_x3<MT, NT> of that shape (4,2 8,2 4,4 2,2 4,1 2,1 8,1)");
-    g_force_b3[0] = mt; g_force_b3[1] = nt;
+    g_force_b3[0] = mt; g_force_b3[1] = nt; g_force_b3[2] = ks;
     return MTV_OK;
 }
 

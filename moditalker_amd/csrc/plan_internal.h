@@ -264,7 +264,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s);          // measured tile per 
 int finish_split_k(mtv_ctx* c, Plan* p);                   // slab + arrival counters shared by the plan's split-K convs
 int run_ops(mtv_ctx* c, Plan* p, hipStream_t s);
 int capture(mtv_ctx* c, Plan* p, hipGraphExec_t* out);
-constexpr long X3_MIN_ROWS = 4096;
+constexpr long X3_MIN_ROWS = 1024;
 bool x3_wanted(long rows);                                  // plan.hip: offer this conv to the split-bf16 kernels?
 int check_ready(mtv_ctx* c, int batch);                     // (also refreshes the split-bf16 weight copies after a weight load)
 int ctx_init_common(mtv_ctx* c);

@@ -238,7 +238,7 @@ def test_autoencoder_on_split_bf16_gemms_vs_reference_golden():
     and extract at the shipped 256x256 geometry against the reference's golden outputs, the same 1e-3 bar as the f32 kernels."""
     from moditalker_amd import _lib
     lib = _lib.load()
-    _lib.check(lib.mtv_debug_force_b3(4, 2), "mtv_debug_force_b3")
+    _lib.check(lib.mtv_debug_force_b3(4, 2, 1), "mtv_debug_force_b3")
     try:
         g = np.load(os.path.join(GOLDEN, "ae.npz"))
         seed, res = int(g["full_seed"]), 256
@@ -253,4 +253,4 @@ def test_autoencoder_on_split_bf16_gemms_vs_reference_golden():
         names = [p["name"] for p in ae.profile(1, False, 1)]
         assert any("gemm" in n for n in names)
     finally:
-        lib.mtv_debug_force_b3(0, 0)
+        lib.mtv_debug_force_b3(0, 0, 1)

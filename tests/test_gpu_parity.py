@@ -421,8 +421,8 @@ def test_batched_eight_clip_plan_vs_reference_golden():
         assert _maxabs(z[k:k + 1], g[f"sample_S{S}"] if k % 2 == 0 else zb) <= SAMPLE_TOL, k
 
 
-@pytest.mark.parametrize("mt,nt", [(4, 2), (2, 2), (2, 1), (8, 2), (4, 4), (8, 1), (4, 1)])
-def test_split_bf16_lds_conv_kernel_vs_reference_golden(mt, nt):
+@pytest.mark.parametrize("mt,nt,ks", [(4, 2, 1), (2, 2, 1), (2, 1, 1), (8, 2, 1), (4, 4, 1), (8, 1, 1), (4, 1, 1), (4, 2, 2), (2, 2, 4), (2, 1, 8)])
+def test_split_bf16_lds_conv_kernel_vs_reference_golden(mt, nt, ks):
     """k_x3_prep + k_conv_x3 (csrc/conv_x3.hip: GroupNorm / SiLU / three-term bf16 split in one elementwise pass, then a
     gathering GEMM on v_mfma_f32_16x16x32_bf16 with both operands by LDS-DMA, six partial products, f32 accumulation) forced onto
     every eligible conv of the base UNet: eps vs the reference golden at t = 999 / 0, the 4-step sample, and a ragged 2-clip
@@ -431,7 +431,7 @@ def test_split_bf16_lds_conv_kernel_vs_reference_golden(mt, nt):
     from moditalker_amd import _lib
     from oracle import ref_unet
     lib = _lib.load()
-    _lib.check(lib.mtv_debug_force_b3(mt, nt), "mtv_debug_force_b3")
+    _lib.check(lib.mtv_debug_force_b3(mt, nt, ks), "mtv_debug_force_b3")
     try:
         g = np.load(os.path.join(GOLDEN, "base.npz"))
         net = _build(BASE_CFG, 7, max_batch=1)
@@ -441,7 +441,8 @@ def test_split_bf16_lds_conv_kernel_vs_reference_golden(mt, nt):
             eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
             assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
         names = [p["name"] for p in net.diffusion_model.profile_forward(1, 1, dev)]
-        assert sum(f"t{mt},{nt},48,1]" in n for n in names) >= 25, "the split-bf16 kernel was not selected"      # (the level-0 convs: rows >= 2048)
+        assert sum(f"t{mt},{nt},48," in n for n in names) >= 25, "the split-bf16 kernel was not selected"
+        assert ks == 1 or sum(f"t{mt},{nt},48,{ks}]" in n for n in names) >= 10, "no K slices"      # (the level-0 convs: rows >= 2048)
         noise = [z.to(dev) for z in filler.noise_list(4, (1, 4, 2048), seed=7, tag="base.S4")]
         dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=4, w=0.0).to(dev)
         assert _maxabs(dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=noise), g["sample_S4"]) <= SAMPLE_TOL
@@ -452,4 +453,4 @@ def test_split_bf16_lds_conv_kernel_vs_reference_golden(mt, nt):
         ref = ref_unet.unet_forward({k: v.cpu() for k, v in net2.state_dict().items()}, cfg, x, cond, ic, t, 24, 8)
         assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
     finally:
-        lib.mtv_debug_force_b3(0, 0)
+        lib.mtv_debug_force_b3(0, 0, 1)

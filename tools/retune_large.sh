@@ -1,6 +1,6 @@
 #!/bin/bash
-# Re-times only the conv shapes of at least 4096 tokens (the ones the split-bf16 kernels of conv_x3.hip are offered for) and keeps
-# every other entry of the committed table: gpurun --timeout 1500 -- 'bash tools/retune_large.sh'.
+# Re-times only the conv shapes of at least 1024 tokens (the ones the split-bf16 kernels of conv_x3.hip are offered for), except
+# the one-clip R = 32 step's (B1, L <= 2048: the headline plan stays as tuned), and keeps every other entry of the committed table: gpurun --timeout 1500 -- 'bash tools/retune_large.sh'.
 # Output: gpurun_out/tune_gfx950.txt (copy it over moditalker_amd/csrc/tune_gfx950.txt).
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -10,7 +10,7 @@ import re
 keep = []
 for line in open("moditalker_amd/csrc/tune_gfx950.txt"):
     m = re.match(r"B(\d+) L(\d+)/", line)
-    if line.startswith("#") or (m and int(m.group(1)) * int(m.group(2)) >= 4096):
+    if line.startswith("#") or (m and int(m.group(1)) * int(m.group(2)) >= 1024 and not (int(m.group(1)) == 1 and int(m.group(2)) <= 2048)):
         continue
     keep.append(line)
 open("gpurun_out/tune_raw.txt", "w").writelines(keep)
