@@ -154,6 +154,10 @@ int mtv_debug_force_lin(int mt, int nt, int nwv);
  * MI355X at every shape measured), 1 = the split-bf16 core k_attention_b3 (csrc/attn_b3.hip) on every eligible launch,
  * -1 = k_attention_b3 for segments of >= 256 keys.  The parity tests run both. */
 int mtv_debug_attention_b3(int mode);
+/* Testing aid: attention launches issued (or captured) after this call compute QK^T on the bf16 matrix pipe through a three-term
+ * split of q and k at f32 accuracy (k_attention<..., QB = 1>: the 8-wave shapes of d = 16 / 32 / 64; PV stays on the f32
+ * instruction): 1 on, 0 off, -1 back to the build default / MTV_ATT_QB. */
+int mtv_debug_attention_qb(int mode);
 
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
 int mtv_set_eager(mtv_ctx* ctx, int eager);

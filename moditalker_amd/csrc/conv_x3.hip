@@ -41,9 +41,6 @@ typedef __attribute__((address_space(3))) char lchar;
 #ifndef X3_PRIO
 #define X3_PRIO 1
 #endif
-#ifndef X3_PIPE
-#define X3_PIPE 1
-#endif
 #ifndef X3_ABLATE
 #define X3_ABLATE 0          // tools/ubench/x3_bench: 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no A pieces, 16 no W pieces
 #endif
@@ -249,7 +246,6 @@ struct X3Shape {
     static constexpr int PA = 6 * MT, PW = 12 * NT, PT = PA + PW, P = (PT + 7) / 8;      // DMA pieces per stage: A, W, all, per wave
     static constexpr int NSMAX = ((int)CONV_X3_MAX_LDS - 13 * 1024) / STAGE;            // (13 KB: the largest row table + statistics + dump)
     static constexpr int NS = NSMAX > X3_NSCAP ? X3_NSCAP : NSMAX;
-    static constexpr bool PIPE = X3_PIPE && (24 * (MT + NT) + 4 * MT * NT <= 184);       // fragment registers double-buffered when they fit
     static_assert(NS >= 2 && (MT % 2) == 0, "tile");
 };
 // LDS: row table [(ntaps + 1)][BM] ints | statistics slots [3][BN / 4][2] doubles | dump (1 KB, target of the padding pieces) | stages
@@ -259,7 +255,6 @@ __host__ __device__ inline int x3_tab_bytes(int BM, int BN, int ntaps) { return 
 constexpr int x3_waitcnt_vm_lgkm0(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4); }
 constexpr int x3_waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }        // ... lgkmcnt = 15: no wait
 
-template <int BYTES>
 __device__ __forceinline__ void x3_dma16(gchar* g, lchar* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
@@ -415,7 +410,7 @@ __global__ __launch_bounds__(512) void k_conv_x3(const X3Args a) {
                 lchar* l = pc_lds[k] < 0 ? lds0 + dump_off : sb + pc_lds[k];
                 if constexpr ((X3_ABLATE & 8) != 0) { if (!pc_isw[k]) continue; }
                 if constexpr ((X3_ABLATE & 16) != 0) { if (pc_isw[k]) continue; }
-                if constexpr (!(X3_ABLATE & 2)) x3_dma16<16>((gchar*)g + pc_v[k], l);
+                if constexpr (!(X3_ABLATE & 2)) x3_dma16((gchar*)g + pc_v[k], l);
             }
             chW += strideW;
             chA += strideA;
@@ -441,7 +436,7 @@ __global__ __launch_bounds__(512) void k_conv_x3(const X3Args a) {
         } else {
 #pragma unroll
             for (int k = 0; k < P; ++k)
-                if constexpr (!(X3_ABLATE & 2)) x3_dma16<16>((gchar*)a.W3 + (unsigned)lane * 16u, lds0 + dump_off);      // keeps the in-flight count constant at the tail
+                if constexpr (!(X3_ABLATE & 2)) x3_dma16((gchar*)a.W3 + (unsigned)lane * 16u, lds0 + dump_off);      // keeps the in-flight count constant at the tail
         }
     };
 

@@ -185,21 +185,54 @@ __device__ __forceinline__ float lane_swap_max32(float x) {
 #define ATT_ACC(x) do { } while (0)
 #endif
 
+typedef __bf16 att_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 att_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned att_u32x4 __attribute__((ext_vector_type(4)));
+typedef float att_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned att_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(att_f32x2{a, b}, att_bf16x2)); }
+// x = x0 + x1 + x2, three bf16 terms (round to nearest even; the residuals are exact): pairs of floats -> packed pairs per plane
+__device__ __forceinline__ void att_split2(float a, float b, unsigned& t0, unsigned& t1, unsigned& t2) {
+    t0 = att_pk(a, b);
+    const float ra = a - __uint_as_float(t0 << 16), rb = b - __uint_as_float(t0 & 0xffff0000u);
+    t1 = att_pk(ra, rb);
+    t2 = att_pk(ra - __uint_as_float(t1 << 16), rb - __uint_as_float(t1 & 0xffff0000u));
+}
+__device__ __forceinline__ void att_split4(const f32x4& v, unsigned (&p0)[2], unsigned (&p1)[2], unsigned (&p2)[2]) {
+    att_split2(v[0], v[1], p0[0], p1[0], p2[0]);
+    att_split2(v[2], v[3], p0[1], p1[1], p2[1]);
+}
+__device__ __forceinline__ void att_split8(const float (&y)[8], att_u32x4& p0, att_u32x4& p1, att_u32x4& p2) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        unsigned t0, t1, t2;
+        att_split2(y[2 * h], y[2 * h + 1], t0, t1, t2);
+        p0[h] = t0;
+        p1[h] = t1;
+        p2[h] = t2;
+    }
+}
+
 // LDS of one k_attention workgroup (floats): K stages | V^T stages | key-part merge records.  KBX = 2 doubles the key block
 // (half the barriers / tile hand-overs per segment; above the 64 KB static limit, hence dynamic LDS throughout).
-template <int D, int QW, int KSP, int KBX>
+// QB = 1: the keys are staged as three bf16 planes (k = k0 + k1 + k2) of KPS bytes per key, for QK^T on the bf16 matrix pipe.
+template <int D, int QW, int KSP, int KBX, int QB = 0>
 struct AttShape {
     static constexpr int KSTR = D + (D >= 16 ? 4 : 0);
     static constexpr int KB = (D >= 128 ? 16 : (D >= 64 ? 32 : (D >= 32 ? 64 : 128))) * KBX;
     static constexpr int VSTR = KB + 4, VROWS = D < 16 ? 16 : D;
     static constexpr int NOB = D >= 16 ? D / 16 : 1, XW = NOB * 4 + 2;
-    static constexpr int KS_FLOATS = 2 * KB * KSTR, VT_FLOATS = 2 * VROWS * VSTR;
+    // bytes per key and plane: D bf16, padded to an odd multiple of 32 bytes (16 keys x {g, g + 1} of a ds_read_b128 lane group
+    // then hit 16 distinct bank quads: 32 / 96 / 160 bytes at d = 16 / 32 / 64)
+    static constexpr int KPS = 16 * (D / 8 + (((D / 8) % 4) == 2 ? 0 : 2));
+    static constexpr int KS_FLOATS = QB ? 2 * 3 * KB * KPS / 4 : 2 * KB * KSTR, VT_FLOATS = 2 * VROWS * VSTR;
     static constexpr int XO_FLOATS = KSP > 1 ? (KSP - 1) * QW * XW * 64 : 4;
     static constexpr size_t BYTES = (size_t)(KS_FLOATS + VT_FLOATS + XO_FLOATS) * 4;
 };
 
-template <int D, int QW, int KSP, int KBX = 1>
+template <int D, int QW, int KSP, int KBX = 1, int QB = 0>
 __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
+    typedef AttShape<D, QW, KSP, KBX, QB> ASH;
+    static_assert(!QB || D == 16 || D == 32 || D == 64, "bf16 QK^T: d = 16, 32, 64");
     touch_kernargs<(int)sizeof(AttnArgs)>();
     ATT_STAMP(0);
     constexpr float LOG2E = 1.4426950408889634f;
@@ -210,8 +243,8 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     // hit 16 distinct bank quads -- (KSTR/4 * j + g) mod 16 must be a permutation of j: KSTR/4 odd.  (D = 16 ran unpadded
     // through round 2's first half: stride 16 floats = a 4-way conflict on every K fragment of the level-0 attentions.)
     constexpr int KSTR = D + (D >= 16 ? 4 : 0);
-    constexpr int KB = AttShape<D, QW, KSP, KBX>::KB;   // keys per block (LDS budget)
-    static_assert(KSTR == AttShape<D, QW, KSP, KBX>::KSTR, "LDS layout");
+    constexpr int KB = ASH::KB;   // keys per block (LDS budget)
+    static_assert(KSTR == ASH::KSTR, "LDS layout");
     constexpr int NKT = KB / 16;                   // 16-key tiles per block
     constexpr int WKT = NKT / KSP;                 // ... of which each wave takes WKT
     static_assert(WKT >= 1, "key split wider than the key block");
@@ -224,8 +257,10 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     typedef float ks_row_t[KB * KSTR];
     typedef float vt_row_t[VROWS * VSTR];
     ks_row_t* Ks = reinterpret_cast<ks_row_t*>(att_smem);                                                       // [2][KB * KSTR]
-    vt_row_t* Vt = reinterpret_cast<vt_row_t*>(att_smem + AttShape<D, QW, KSP, KBX>::KS_FLOATS);                // [2][VROWS * VSTR]
-    float* Xo = att_smem + AttShape<D, QW, KSP, KBX>::KS_FLOATS + AttShape<D, QW, KSP, KBX>::VT_FLOATS;
+    vt_row_t* Vt = reinterpret_cast<vt_row_t*>(att_smem + ASH::KS_FLOATS);                // [2][VROWS * VSTR]
+    float* Xo = att_smem + ASH::KS_FLOATS + ASH::VT_FLOATS;
+    constexpr int KPS = ASH::KPS, KPL = KB * KPS;      // QB: bytes per key / per plane of a stage
+    char* const Kb = reinterpret_cast<char*>(att_smem);                                   // QB: [2 stages][3 planes][KB][KPS]
     constexpr int XW = NOB * 4 + 2;                // merge record per lane: m, l, O^T registers
 
     const int tid = threadIdx.x;
@@ -275,11 +310,25 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     // branches with a full wait each), requested together with the first K/V tile; masked when they are consumed
     typedef float qvec_t __attribute__((ext_vector_type(VW)));
     qvec_t qraw[NV];
+    // QB: the B operand of v_mfma_f32_16x16x32_bf16 holds 8 consecutive k-dim values per lane.  d = 16: the 32-wide k dim carries
+    // TWO products of 16 (lanes g < 2 | g >= 2), d index 8 (g & 1) + e; d >= 32: one product per 32-wide step, d index 32 ks + 8 g + e.
+    constexpr int NKS = D >= 32 ? D / 32 : 1;       // 32-wide k steps
+    f32x4 qb_raw[QB ? NKS : 1][2];
     const bool qok = q0 + j < len;
     {
-        const float* qp = base + (size_t)(start + (qok ? q0 + j : 0)) * RS + VW * g;
+        const float* qrow = base + (size_t)(start + (qok ? q0 + j : 0)) * RS;
+        if constexpr (QB) {
 #pragma unroll
-        for (int u = 0; u < NV; ++u) qraw[u] = *reinterpret_cast<const qvec_t*>(qp + 16 * u);
+            for (int ks = 0; ks < NKS; ++ks) {
+                const float* qp = qrow + (D == 16 ? 8 * (g & 1) : 32 * ks + 8 * g);
+                qb_raw[ks][0] = *reinterpret_cast<const f32x4*>(qp);
+                qb_raw[ks][1] = *reinterpret_cast<const f32x4*>(qp + 4);
+            }
+        } else {
+            const float* qp = qrow + VW * g;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) qraw[u] = *reinterpret_cast<const qvec_t*>(qp + 16 * u);
+        }
     }
     f32x4 oacc[NOB];
 #pragma unroll
@@ -309,7 +358,17 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
             const int key = e / QPR, qd = e - key * QPR;
             if (e < KB * QPR) {
                 const bool in = kb + key < klen;
-                *reinterpret_cast<f32x4*>(&Ks[buf][key * KSTR + qd * 4]) = in ? kreg[r] * scale : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 kq = in ? kreg[r] * scale : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (QB) {       // three bf16 terms of the 4 values, 8 bytes per plane
+                    unsigned p0[2], p1[2], p2[2];
+                    att_split4(kq, p0, p1, p2);
+                    char* kd = Kb + (size_t)buf * 3 * KPL + key * KPS + qd * 8;
+                    *reinterpret_cast<uint2*>(kd) = make_uint2(p0[0], p0[1]);
+                    *reinterpret_cast<uint2*>(kd + KPL) = make_uint2(p1[0], p1[1]);
+                    *reinterpret_cast<uint2*>(kd + 2 * KPL) = make_uint2(p2[0], p2[1]);
+                } else {
+                    *reinterpret_cast<f32x4*>(&Ks[buf][key * KSTR + qd * 4]) = kq;
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) Vt[buf][(qd * 4 + c) * VSTR + key] = in ? vreg[r][c] : 0.f;
             }
@@ -319,10 +378,28 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     ATT_STAMP(1);
     gload(0);
     float qreg[NV][VW];
+    att_bf16x8 qf[QB ? NKS : 1][3];          // QB, d >= 32: the terms a0, a1, a2 of the step; d = 16: [a0|a0], [a1|a1], [a0|a2]
+    if constexpr (QB) {
 #pragma unroll
-    for (int u = 0; u < NV; ++u)
+        for (int ks = 0; ks < NKS; ++ks) {
+            float y[8];
 #pragma unroll
-        for (int e = 0; e < VW; ++e) qreg[u][e] = qok ? qraw[u][e] * scale * LOG2E : 0.f;   // scores in log2 units
+            for (int e = 0; e < 4; ++e) {
+                y[e] = qok ? qb_raw[ks][0][e] * scale * LOG2E : 0.f;
+                y[4 + e] = qok ? qb_raw[ks][1][e] * scale * LOG2E : 0.f;
+            }
+            att_u32x4 a0, a1, a2;
+            att_split8(y, a0, a1, a2);
+            qf[ks][0] = __builtin_bit_cast(att_bf16x8, a0);
+            qf[ks][1] = __builtin_bit_cast(att_bf16x8, a1);
+            qf[ks][2] = __builtin_bit_cast(att_bf16x8, (D == 16 && g < 2) ? a0 : a2);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) qreg[u][e] = qok ? qraw[u][e] * scale * LOG2E : 0.f;   // scores in log2 units
+    }
     lstore(0, 0);
     __syncthreads();
     ATT_STAMP(2);
@@ -353,8 +430,49 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         // S^T tiles.  A dependent v_mfma_f32_16x16x4_f32 issues 40 cycles after its producer, an independent one after 32
         // (MI355X_MICROARCH.md): the MFMAs are therefore emitted round-robin over >= 2 independent accumulators -- the
         // wave's WKT tiles, or, with a single tile, the even / odd fragments of the head dimension (summed afterwards).
-        constexpr int US = (WKT == 1 && NV >= 2) ? 2 : 1;
+        constexpr int US = (!QB && WKT == 1 && NV >= 2) ? 2 : 1;
         f32x4 sacc[WKT][US];
+        if constexpr (QB) {
+            // S^T = K Q^T on v_mfma_f32_16x16x32_bf16 at f32 accuracy: k = c0 + c1 + c2, q = a0 + a1 + a2, products a0c2, a2c0, a1c1,
+            // a1c0, a0c1, a0c0 (small first).  d = 16: the k dim holds two 16-wide products per instruction -- [c2|c0].[a0|a2],
+            // [c0|c1].[a1|a1], [c0|c1].[a0|a0]: 3 MFMAs of 16 cycles instead of 4 f32 ones of 32.  d >= 32: six per 32-wide step.
+            const char* kst = Kb + (size_t)buf * 3 * KPL;
+            if constexpr (D == 16) {
+                att_bf16x8 f1[WKT], f3[WKT];
+#pragma unroll
+                for (int w = 0; w < WKT; ++w) {
+                    const char* kp = kst + ((kh * WKT + w) * 16 + j) * KPS + (g & 1) * 16;
+                    f1[w] = *reinterpret_cast<const att_bf16x8*>(kp + (g < 2 ? 0 : KPL));              // [c0 | c1]
+                    f3[w] = *reinterpret_cast<const att_bf16x8*>(kp + (g < 2 ? 2 * KPL : 0));          // [c2 | c0]
+                    sacc[w][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int w = 0; w < WKT; ++w) sacc[w][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f3[w], qf[0][2], sacc[w][0], 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < WKT; ++w) sacc[w][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[w], qf[0][1], sacc[w][0], 0, 0, 0);
+#pragma unroll
+                for (int w = 0; w < WKT; ++w) sacc[w][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1[w], qf[0][0], sacc[w][0], 0, 0, 0);
+            } else {
+                att_bf16x8 kf[WKT][NKS][3];
+#pragma unroll
+                for (int w = 0; w < WKT; ++w) {
+                    const char* kp = kst + ((kh * WKT + w) * 16 + j) * KPS + g * 16;
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) kf[w][ks][pl] = *reinterpret_cast<const att_bf16x8*>(kp + pl * KPL + ks * 64);
+                    sacc[w][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                constexpr int PK[6] = {2, 1, 0, 1, 0, 0}, PQ[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                        for (int w = 0; w < WKT; ++w)
+                            sacc[w][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[w][ks][PK[t]], qf[ks][PQ[t]], sacc[w][0], 0, 0, 0);
+            }
+        } else {
         float kv[WKT][NV][VW];
 #pragma unroll
         for (int w = 0; w < WKT; ++w) {
@@ -381,6 +499,7 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
 #pragma unroll
                     for (int w = 0; w < WKT; ++w)
                         if (u0 + c < NV) sacc[w][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[w][u0 + c][e], qreg[u0 + c][e], sacc[w][c], 0, 0, 0);
+        }
 #pragma unroll
         for (int w = 0; w < WKT; ++w) {
             const int kt = kh * WKT + w;
@@ -516,18 +635,23 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     ATT_STAMP(5);
 }
 
-template <int D, int QW, int KSP, int KBX>
+template <int D, int QW, int KSP, int KBX, int QB = 0>
 static hipError_t att_launch(const AttnArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((k_attention<D, QW, KSP, KBX>), grid, dim3(64 * QW * KSP), (AttShape<D, QW, KSP, KBX>::BYTES), s, a);
+    hipLaunchKernelGGL((k_attention<D, QW, KSP, KBX, QB>), grid, dim3(64 * QW * KSP), (AttShape<D, QW, KSP, KBX, QB>::BYTES), s, a);
     return hipGetLastError();
 }
-template <int D, int QW, int KSP, int KBX>
+template <int D, int QW, int KSP, int KBX, int QB = 0>
 static hipError_t att_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<D, QW, KSP, KBX>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<D, QW, KSP, KBX, QB>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 // Dynamic LDS above 64 KB must be opted into once per kernel (the KBX = 2 shapes); done at context creation, never under capture.
 hipError_t attn_init_attrs() {
     hipError_t e;
+#define MTV_QB_ATTR(D, QW, KSP, KBX) if ((e = att_attr<D, QW, KSP, KBX, 1>()) != hipSuccess) return e
+    MTV_QB_ATTR(16, 4, 2, 1); MTV_QB_ATTR(16, 4, 2, 2); MTV_QB_ATTR(16, 2, 4, 1);
+    MTV_QB_ATTR(32, 4, 2, 1); MTV_QB_ATTR(32, 4, 2, 2); MTV_QB_ATTR(32, 2, 4, 1);
+    MTV_QB_ATTR(64, 4, 2, 1); MTV_QB_ATTR(64, 4, 2, 2);
+#undef MTV_QB_ATTR
     if ((e = att_attr<16, 4, 2, 2>()) != hipSuccess) return e;
     if ((e = att_attr<16, 1, 4, 2>()) != hipSuccess) return e;
     if ((e = att_attr<32, 4, 2, 2>()) != hipSuccess) return e;
@@ -537,6 +661,8 @@ hipError_t attn_init_attrs() {
     return attn_b3_init_attrs();
 }
 
+int g_attn_qb_default = 1;    // QK^T on the bf16 pipe (d = 16 / 32; d = 64 only when asked for) unless MTV_ATT_QB / mtv_debug_attention_qb say otherwise
+int g_attn_qb_force = -1;     // mtv_debug_attention_qb: -1 = environment / default, 0 off, 1 on
 int g_attn_b3_mode = -2;        // -2: not yet read from the environment
 int g_attn_b3_min_keys = 256;
 
@@ -613,26 +739,39 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
         for (int i = 0; i < a.nseg; ++i) maxk = a.seg_len[i] > maxk ? a.seg_len[i] : maxk;
     const int base_kb = d >= 64 ? 32 : (d >= 32 ? 64 : 128);
     const bool big = kbx_env == 2 && !half && (d == 16 || d == 32 || d == 64) && (long)nblk * a.H * a.B <= 256 && maxk > base_kb;
+    // QK^T on the bf16 matrix pipe (three-term split of q and k, f32 accuracy; k_attention<..., QB = 1>) for the 8-wave shapes of
+    // d = 16 / 32 / 64: MTV_ATT_QB=0 switches it off, =1 on everywhere.
+    // Default: on for d = 16 / 32 (level-0 / -1 attentions: -12 ... -17 % per launch at 2048+ keys, profiles/r03_attention_qb.txt),
+    // off for d = 64 (the autoencoder: bound by its V^T staging, no gain) unless asked for explicitly.
+    static int qb_env = -1, qb_explicit = 0;
+    if (qb_env < 0) {
+        qb_env = g_attn_qb_default;
+        if (const char* e = getenv("MTV_ATT_QB")) { qb_env = atoi(e) != 0 ? 1 : 0; qb_explicit = 1; }
+    }
+    const bool qb_asked = g_attn_qb_force == 1 || (g_attn_qb_force < 0 && qb_explicit && qb_env == 1);
+    const bool qb = d == 64 ? qb_asked : (g_attn_qb_force >= 0 ? g_attn_qb_force : qb_env) != 0;
 #define MTV_ATT_GO(D, QW, KSP, KBX) return att_launch<D, QW, KSP, KBX>(a, grid, s)
+#define MTV_ATT_GOQ(D, QW, KSP, KBX) do { if (qb) return att_launch<D, QW, KSP, KBX, 1>(a, grid, s); return att_launch<D, QW, KSP, KBX>(a, grid, s); } while (0)
     switch (d) {
         case 4: if (wide) MTV_ATT_GO(4, 4, 2, 1); else MTV_ATT_GO(4, 1, 4, 1);
         case 8: if (wide) MTV_ATT_GO(8, 4, 2, 1); else MTV_ATT_GO(8, 1, 4, 1);
         case 16:
-            if (half) MTV_ATT_GO(16, 2, 4, 1);
-            if (wide) { if (big) MTV_ATT_GO(16, 4, 2, 2); else MTV_ATT_GO(16, 4, 2, 1); }
+            if (half) MTV_ATT_GOQ(16, 2, 4, 1);
+            if (wide) { if (big) MTV_ATT_GOQ(16, 4, 2, 2); else MTV_ATT_GOQ(16, 4, 2, 1); }
             if (big) MTV_ATT_GO(16, 1, 4, 2); else MTV_ATT_GO(16, 1, 4, 1);
         case 32:
-            if (half) MTV_ATT_GO(32, 2, 4, 1);
-            if (wide) { if (big) MTV_ATT_GO(32, 4, 2, 2); else MTV_ATT_GO(32, 4, 2, 1); }
+            if (half) MTV_ATT_GOQ(32, 2, 4, 1);
+            if (wide) { if (big) MTV_ATT_GOQ(32, 4, 2, 2); else MTV_ATT_GOQ(32, 4, 2, 1); }
             if (big) MTV_ATT_GO(32, 1, 4, 2); else MTV_ATT_GO(32, 1, 4, 1);
         case 48: if (wide) MTV_ATT_GO(48, 4, 2, 1); else MTV_ATT_GO(48, 1, 4, 1);   // the autoencoder's quant stacks (autoencoder_vit.py:140-142: dim_head = 384/8)
         case 64:
-            if (wide) { if (big) MTV_ATT_GO(64, 4, 2, 2); else MTV_ATT_GO(64, 4, 2, 1); }
+            if (wide) { if (big) MTV_ATT_GOQ(64, 4, 2, 2); else MTV_ATT_GOQ(64, 4, 2, 1); }
             if (big) MTV_ATT_GO(64, 1, 4, 2); else MTV_ATT_GO(64, 1, 2, 1);
         case 128: MTV_ATT_GO(128, 4, 1, 1);
         default: return hipErrorInvalidValue;
     }
 #undef MTV_ATT_GO
+#undef MTV_ATT_GOQ
 }
 
 // =====================================================================================

@@ -284,6 +284,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 bool attn_b3_eligible(const AttnArgs& a);
 hipError_t launch_attention_b3(const AttnArgs& a, hipStream_t s);
 hipError_t attn_b3_init_attrs();
+extern int g_attn_qb_default, g_attn_qb_force;   // k_attention<..., QB>: QK^T on the bf16 matrix pipe (kernels.hip)
 extern int g_attn_b3_mode;          // -1 auto (segments of >= g_attn_b3_min_keys keys), 0 never, 1 every eligible launch (mtv_debug_attention_b3 / MTV_ATT_B3)
 extern int g_attn_b3_min_keys;
 hipError_t launch_linear(const LinearArgs& a, hipStream_t s);

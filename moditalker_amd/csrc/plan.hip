@@ -1525,6 +1525,12 @@ int mtv_debug_attention_b3(int mode) {
     return MTV_OK;
 }
 
+int mtv_debug_attention_qb(int mode) {
+    if (mode < -1 || mode > 1) return fail(MTV_ERR_INVALID, "mode must be -1 (default), 0 (off) or 1 (on)");
+    g_attn_qb_force = mode;
+    return MTV_OK;
+}
+
 int mtv_debug_force_b3(int mt, int nt, int ks) {
     if (mt == 0) { g_force_b3[0] = 0; return MTV_OK; }
     if (!(ks == 1 || ks == 2 || ks == 4 || ks == 8)) return fail(MTV_ERR_INVALID, "K slices must be 1, 2, 4 or 8");

@@ -254,3 +254,24 @@ def test_autoencoder_on_split_bf16_gemms_vs_reference_golden():
         assert any("gemm" in n for n in names)
     finally:
         lib.mtv_debug_force_b3(0, 0, 1)
+
+
+def test_autoencoder_on_bf16_pipe_qk_attention_vs_reference_golden():
+    """The autoencoder's d = 64 attentions with QK^T on the bf16 matrix pipe (k_attention<64, ., ., ., QB = 1>): decode_from_sample
+    and extract at the shipped 256x256 geometry against the reference's golden outputs."""
+    from moditalker_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_attention_qb(1), "mtv_debug_attention_qb")
+    try:
+        g = np.load(os.path.join(GOLDEN, "ae.npz"))
+        seed, res = int(g["full_seed"]), 256
+        ae = _ae(res, seed, 1)
+        r = res // 8
+        lat = filler.uniform_pm1("ae.full.latent", (1, 4, r * r + 2 * 16 * r), seed)
+        frames = ae.decode_from_sample(lat.to(_dev())).cpu()
+        assert float((frames[:, :, ::5, ::5] - torch.from_numpy(g["full_frames_sub5"])).abs().max()) <= TOL
+        vid = filler.uniform_pm1("ae.full.video", (1, 3, 16, res, res), seed)
+        z = ae.extract(vid.to(_dev())).cpu()
+        assert float((z - torch.from_numpy(g["full_extract"])).abs().max()) <= TOL
+    finally:
+        lib.mtv_debug_attention_qb(-1)

@@ -389,6 +389,38 @@ def test_split_bf16_attention_core_vs_reference_golden():
         lib.mtv_debug_attention_b3(0)
 
 
+def test_bf16_pipe_qk_attention_vs_reference_golden():
+    """k_attention<..., QB = 1> (csrc/kernels.hip: QK^T on v_mfma_f32_16x16x32_bf16 through a three-term split of q and k --
+    d = 16: two 16-wide products per instruction; PV unchanged on the f32 instruction) switched on for every 8-wave attention
+    shape of the base UNet: eps vs the reference golden at t = 999 / 500 / 0, the metric's own 250-step sample vs the reference
+    golden, and a ragged 2-clip geometry (partial key blocks, partial query tiles) vs the oracle."""
+    from moditalker_amd import _lib
+    from oracle import ref_unet
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_attention_qb(1), "mtv_debug_attention_qb")
+    try:
+        g = np.load(os.path.join(GOLDEN, "base.npz"))
+        net = _build(BASE_CFG, 7, max_batch=1)
+        dev = _dev()
+        x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+        for tv in (999, 500, 0):
+            eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
+            assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
+        for S in (4, 250):
+            noise = filler.noise_list(S, (1, 4, 2048), seed=7, tag=f"base.S{S}")
+            dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=S, w=0.0).to(dev)
+            z = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=[n.to(dev) for n in noise])
+            assert _maxabs(z, g[f"sample_S{S}"]) <= SAMPLE_TOL, S
+        cfg = dict(BASE_CFG, image_size=24)            # 24x24 | 8x24 | 8x24 planes: segments of 576 / 192 / 960 keys ... down to 9 / 3
+        net2 = _build(cfg, 21, frames=8, max_batch=2)
+        x, cond, ic = filler.synthetic_inputs(2, 24, 8, seed=5, tag="lds")
+        t = torch.tensor([700, 3])
+        ref = ref_unet.unet_forward({k: v.cpu() for k, v in net2.state_dict().items()}, cfg, x, cond, ic, t, 24, 8)
+        assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
+    finally:
+        lib.mtv_debug_attention_qb(-1)
+
+
 def test_batched_eight_clip_plan_vs_reference_golden():
     """The B = 8 plan bench.py's `batched_info` times (its own tiles: k_conv_lds on the large convs, small key blocks in the
     attention), untouched by any forcing: clips 0, 2, 4, 6 carry the reference golden's inputs and noise and must reproduce
