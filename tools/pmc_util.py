@@ -71,7 +71,8 @@ for k, f in sorted(fam.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))
     va = f["SQ_ACTIVE_INST_VALU"] / f["SQ_WAVE_CYCLES"] if f["SQ_WAVE_CYCLES"] else 0.0
     ns = len(steps)
     print(f"  {k:14s} {f['n'] / ns:8.0f} {util:9.3f} {co:16.3f} {va:23.3f} {f['SQ_INSTS_MFMA'] / ns:11.0f} {f['SQ_INSTS_VALU'] / ns:11.0f}")
-    out[k] = dict(launches_per_step=round(f["n"] / ns), mfma_util=round(util, 4), coexec_over_mfma_busy=round(co, 4))
+    out[k] = dict(launches_per_step=round(f["n"] / ns), mfma_util_eager=round(util, 4), coexec_over_mfma_busy=round(co, 4),
+                  mfma_busy_cycles_per_step=round(f["SQ_VALU_MFMA_BUSY_CYCLES"] / ns), mfma_insts_per_step=round(f["SQ_INSTS_MFMA"] / ns))
 if a.fetch and a.write and a.trace:
     def per_family(path):
         rows = list(csv.DictReader(open(path)))
@@ -97,5 +98,8 @@ if a.fetch and a.write and a.trace:
         print(f"  {k:14s} FETCH {F[k] / 1e6:8.1f} MB  WRITE {W.get(k, 0) / 1e6:7.1f} MB  time {t * 1e6:8.1f} us/step  -> {b / t / 1e9:8.1f} GB/s")
         out.setdefault(k, {}).update(fetch_raw_MB_per_step=round(F[k] / 1e6, 1), write_raw_MB_per_step=round(W.get(k, 0) / 1e6, 1),
                                      ms_per_step_trace=round(t * 1e3, 4), hbm_counter_GBs=round(b / t / 1e9, 1))
+        if "mfma_busy_cycles_per_step" in out[k]:      # matrix-pipe busy cycles (all SIMDs) over the SIMD-cycles of the family's graph-replay time at 2.4 GHz
+            out[k]["mfma_util"] = round(out[k]["mfma_busy_cycles_per_step"] / (t * 2.4e9 * 1024), 4)
+            print(f"  {k:14s} matrix-pipe busy / (kernel-trace family time x 2.4 GHz x 1024 SIMDs) = {out[k]['mfma_util']:.3f}")
 if a.json:
     json.dump(out, open(a.json, "w"), indent=1)
