@@ -10,8 +10,7 @@ O=gpurun_out/final; rm -rf $O; mkdir -p $O
 # (tiles come from the committed table moditalker_amd/csrc/tune_gfx950.txt: no tuning inside the profiled processes)
 # 2. per-launch hipEvent table (op names / shapes / tiles; also the join key for per_op_rocprof.py)
 timeout 120 python tools/profile_ops.py --iters 20 > $O/r${NN}_per_launch_hipevents.txt 2>$O/ops.err
-# 3. the bench line (N=1, with cpu_baseline and batched_info)
-timeout 400 python bench.py --steps 250 --warmup 25 > $O/r${NN}_bench_n1.json 2>$O/bench.err
+# 3. (the bench line comes after the counter passes: it quotes profiles/pmc_traffic.json, which step 5b refreshes)
 # 4. kernel trace + stats of the same command
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- \
     python bench.py --steps 100 --warmup 10 --no-cpu-baseline --batched-clips 0 > $O/kt.log 2>&1
@@ -37,6 +36,9 @@ MTV_EAGER=1 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES 
 echo "pmc SQ rc=$?"
 PS=$(find $O/pmc_SQ -name '*counter_collection.csv' | head -1)
 python tools/pmc_util.py $PS --launches $NL --fetch $PF --write $PW --trace $KT --json $O/pmc_util.json > $O/r${NN}_pmc_util.txt 2>&1
+python tools/update_pmc_traffic.py $O/pmc_util.json "round $NN (tools/make_profiles.sh)" "$(git rev-parse --short HEAD 2>/dev/null)"; cp profiles/pmc_traffic.json $O/pmc_traffic.json
+# 3. the bench line (N=1, with cpu_baseline and batched_info), quoting the counters just collected
+timeout 500 python bench.py --steps 250 --warmup 25 > $O/r${NN}_bench_n1.json 2>$O/bench.err
 # 5c. does --pmc survive a hipGraph replay on this image?  (round 2: segfault at the first replay.)  One short try, graph mode.
 timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_graph -o p -- \
     python bench.py --steps 10 --warmup 2 --ramp-steps 5 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_graph.log 2>&1
