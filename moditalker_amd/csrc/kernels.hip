@@ -732,13 +732,13 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     static int kbx_env = -1;
     if (kbx_env < 0) {
         kbx_env = 2;
-        if (const char* e = getenv("MTV_ATT_KBX")) kbx_env = atoi(e) == 1 ? 1 : 2;
+        if (const char* e = getenv("MTV_ATT_KBX")) kbx_env = atoi(e) == 1 ? 1 : (atoi(e) == 3 ? 3 : 2);      // (3: double blocks at every grid size -- experiment)
     }
     int maxk = a.kv ? a.Lkv : a.seg_uniform;
     if (!a.kv && !a.seg_uniform)
         for (int i = 0; i < a.nseg; ++i) maxk = a.seg_len[i] > maxk ? a.seg_len[i] : maxk;
     const int base_kb = d >= 64 ? 32 : (d >= 32 ? 64 : 128);
-    const bool big = kbx_env == 2 && !half && (d == 16 || d == 32 || d == 64) && (long)nblk * a.H * a.B <= 256 && maxk > base_kb;
+    const bool big = kbx_env >= 2 && !half && (d == 16 || d == 32 || d == 64) && ((long)nblk * a.H * a.B <= 256 || kbx_env == 3) && maxk > base_kb;
     // QK^T on the bf16 matrix pipe (three-term split of q and k, f32 accuracy; k_attention<..., QB = 1>) for the 8-wave shapes of
     // d = 16 / 32 / 64: MTV_ATT_QB=0 switches it off, =1 on everywhere.
     // Default: on for d = 16 / 32 (level-0 / -1 attentions: -12 ... -17 % per launch at 2048+ keys, profiles/r03_attention_qb.txt),
