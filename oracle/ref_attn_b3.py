@@ -40,3 +40,33 @@ def attention_split_bf16(q, k, v):
         t = pt[ip] @ vt[iv]
         o = t if o is None else o + t
     return o / l
+
+
+def attention_qk_split_bf16(q, k, v):
+    """The shipped hybrid (k_attention<..., QB = 1>, csrc/kernels.hip): QK^T from three bf16 terms of q and k (six products, small
+    first), softmax and PV in fp32."""
+    d = q.shape[-1]
+    sc = d ** -0.25
+    qt = split_terms(q * (sc * math.log2(math.e)), 3)
+    kt = split_terms(k * sc, 3)
+    s = None
+    for ik, iq in QK_PAIRS:
+        p = qt[iq] @ kt[ik].transpose(-1, -2)
+        s = p if s is None else s + p
+    m = s.max(-1, keepdim=True).values
+    p = torch.exp2(s - m)
+    return (p @ v) / p.sum(-1, keepdim=True)
+
+
+CONV_PAIRS = [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]          # (activation term, weight term): k_conv_x3's order
+
+
+def gemm_split_bf16(a, w):
+    """k_conv_x3's arithmetic (csrc/conv_x3.hip): a [M, K], w [K, N] fp32, both as three bf16 terms, six partial products with fp32
+    accumulation (the MFMA's own summation order inside a product is not modelled: torch.matmul's stands in)."""
+    at, wt = split_terms(a, 3), split_terms(w, 3)
+    o = None
+    for ia, iw in CONV_PAIRS:
+        t = at[ia] @ wt[iw]
+        o = t if o is None else o + t
+    return o

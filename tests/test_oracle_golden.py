@@ -159,3 +159,27 @@ def test_split_bf16_attention_emulation():
         # a ONE-term probability (plain bf16 P) would not do: three orders of magnitude worse
         p1 = ref_attn_b3.split_terms(torch.softmax((q * sc) @ (k * sc).transpose(-1, -2), -1), 1)[0] @ v
         assert float((p1.double() - w64).abs().max()) > 50 * e32
+
+
+def test_split_bf16_conv_and_qk_emulation():
+    """The arithmetic of the two split-bf16 forms that ship -- k_conv_x3's GEMM (activations and weights as three bf16 terms, six
+    products) and k_attention<QB = 1>'s QK^T -- keeps fp32-class accuracy against fp64: within 4x of plain fp32's error, where two
+    terms per operand (three products) are an order of magnitude off (random operands: the errors average over K)."""
+    from oracle import ref_attn_b3
+    torch.manual_seed(1)
+    for M, K, N in ((256, 1152, 128), (128, 4608, 256), (512, 384, 384)):
+        a, w = torch.randn(M, K), torch.randn(K, N) * K ** -0.5
+        w64 = a.double() @ w.double()
+        e32 = float(((a @ w).double() - w64).abs().max())
+        e3 = float((ref_attn_b3.gemm_split_bf16(a, w).double() - w64).abs().max())
+        assert e3 <= 4.0 * e32 + 1e-6, (M, K, N, e32, e3)
+        at, wt = ref_attn_b3.split_terms(a, 2), ref_attn_b3.split_terms(w, 2)
+        e2 = float(((at[0] @ wt[0] + at[0] @ wt[1] + at[1] @ wt[0]).double() - w64).abs().max())
+        assert e2 > 5 * e32, (e2, e32)
+    for L, d in ((1024, 16), (512, 32), (256, 64)):
+        q, k, v = torch.randn(4, L, d) * 1.5, torch.randn(4, L, d) * 1.5, torch.randn(4, L, d)
+        sc = d ** -0.25
+        w64 = torch.softmax((q.double() * sc) @ (k.double() * sc).transpose(-1, -2), -1) @ v.double()
+        e32 = float(((torch.softmax((q * sc) @ (k * sc).transpose(-1, -2), -1) @ v).double() - w64).abs().max())
+        eqb = float((ref_attn_b3.attention_qk_split_bf16(q, k, v).double() - w64).abs().max())
+        assert eqb <= 4.0 * e32 + 1e-6, (L, d, e32, eqb)
