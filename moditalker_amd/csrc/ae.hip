@@ -302,8 +302,10 @@ struct AeBuilder {
     static int pad64(int n) { return (n + 63) / 64 * 64; }
 
     // out[b][tok][:N] = in[b][gather(tok)][:K] @ W + bias (+ res[b][tok][:N]); rows = tokens per batch element
-    void gemm(const std::string& name, const float* in, int K, const float* W, int ld, const float* bias, int N, float* out,
-              int rows, const float* res = nullptr, const int* gather = nullptr, int batch = -1) {
+    // geglu_h != nullptr: `in` is GEGLU(geglu_h) -- when the GEMM runs on the split-bf16 pair its elementwise pass computes that itself
+    // (x3_fused_geglu) and the separate k_geglu launch that fills `in` is skipped
+    std::shared_ptr<ConvOp> gemm(const std::string& name, const float* in, int K, const float* W, int ld, const float* bias, int N, float* out,
+              int rows, const float* res = nullptr, const int* gather = nullptr, int batch = -1, const float* geglu_h = nullptr) {
         ConvArgs a{};
         a.ntaps = 1;
         a.B = batch < 0 ? B : batch;
@@ -334,7 +336,15 @@ struct AeBuilder {
         const double bytes = 4.0 * ((double)K * N + N) + 4.0 * a.B * ((double)rows * K + (double)rows * N * (res ? 2 : 1));
         char tag[64];
         snprintf(tag, sizeof tag, "[%dx%d k%d]", a.B * rows, N, K);
-        push(op->base_name + tag, [op](hipStream_t s) { return launch_conv(op->a, op->t, s); }, flops, bytes);
+        if (geglu_h)
+            push(op->base_name + tag, [op, geglu_h](hipStream_t s) { return x3_fused_geglu(*op) ? launch_conv_x3_geglu(op->a, op->t, geglu_h, s) : launch_conv(op->a, op->t, s); }, flops, bytes);
+        else
+            push(op->base_name + tag, [op](hipStream_t s) { return launch_conv(op->a, op->t, s); }, flops, bytes);
+        return op;
+    }
+    static bool x3_fused_geglu(const ConvOp& op) {
+        static const bool off = getenv("MTV_AE_NO_GEGLU_FUSION") != nullptr;
+        return !off && op.t.NW == 48 && !op.a.gather && conv_x3_eligible(op.a) && op.a.x3 != nullptr;
     }
 
     float* lin_w(const std::string& key, int N, int K, int* ld_out) {        // Linear [N][K] -> [K][ld]
@@ -397,10 +407,11 @@ struct AeBuilder {
             const float* b1 = vec(p + "2.fn.net.0.bias", 8 * C);
             gemm(nm + ".ff1", ln, C, W1, ld1, b1, 8 * C, hid, D.ntok);
             const int half = 4 * C;
-            push("geglu:" + nm, [=](hipStream_t s) { return launch_geglu(hid, gl, ntok, half, 0, s); }, 0.0, 4.0 * ntok * 12 * C);
+            auto ff2 = std::make_shared<std::shared_ptr<ConvOp>>();      // (the GEGLU launch comes first in the plan, the GEMM it may fold into second)
+            push("geglu:" + nm, [=](hipStream_t s) { return *ff2 && x3_fused_geglu(**ff2) ? hipSuccess : launch_geglu(hid, gl, ntok, half, 0, s); }, 0.0, 4.0 * ntok * 12 * C);
             float* W2 = lin_w(p + "2.fn.net.3.weight", C, 4 * C, &ld2);
             const float* b2 = vec(p + "2.fn.net.3.bias", C);
-            gemm(nm + ".ff2", gl, 4 * C, W2, ld2, b2, C, x, D.ntok, x);
+            *ff2 = gemm(nm + ".ff2", gl, 4 * C, W2, ld2, b2, C, x, D.ntok, x, nullptr, -1, hid);
         }
     }
 

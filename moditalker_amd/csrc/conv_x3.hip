@@ -45,6 +45,7 @@ typedef __attribute__((address_space(3))) char lchar;
 #define X3_ABLATE 0          // tools/ubench/x3_bench: 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no A pieces, 16 no W pieces
 #endif
 
+__device__ __forceinline__ float x3_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }      // (= ae.hip's gelu_erf)
 __device__ __forceinline__ float x3_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ unsigned x3_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
 __device__ __forceinline__ float x3_lo(unsigned p) { return __uint_as_float(p << 16); }
@@ -79,6 +80,7 @@ struct X3Prep {
     unsigned rowsM, rowsS;
     int tilesM, tilesS;       // 64-row blocks per clip
     int cbM, cbS;             // 32-channel blocks
+    int geglu;                // 1: src[0] is a GEGLU pre-activation [rows][2 Cmain]; the element is h[c] * gelu(h[Cmain + c]) (vit_modules.py:88-91)
 };
 
 constexpr int X3P_TS = 66;    // items per (plane, k-group) row of the transpose tile (64 + 2: the four k-groups of a row land in different banks)
@@ -113,11 +115,22 @@ __global__ __launch_bounds__(256) void k_x3_prep(const X3Prep a) {
     const int c = 32 * cb + 8 * kg;
     f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
     if (tok < L) {
-        const bool second = c >= C0;
-        const float* sp = second ? s1 : s0;
-        const int Cp = second ? C1 : C0, cc = second ? c - C0 : c;
-        u0 = *reinterpret_cast<const f32x4*>(sp + ((size_t)b * L + tok) * Cp + cc);
-        u1 = *reinterpret_cast<const f32x4*>(sp + ((size_t)b * L + tok) * Cp + cc + 4);
+        if (a.geglu) {        // the GEGLU of the autoencoder's feed-forward, fused: the same expression, in the same order, as ae.hip's k_geglu
+            const float* hp = s0 + ((size_t)b * L + tok) * (2 * (size_t)C) + c;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(hp), a1 = *reinterpret_cast<const f32x4*>(hp + 4);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(hp + C), g1 = *reinterpret_cast<const f32x4*>(hp + C + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u0[e] = a0[e] * x3_gelu_erf(g0[e]);
+                u1[e] = a1[e] * x3_gelu_erf(g1[e]);
+            }
+        } else {
+            const bool second = c >= C0;
+            const float* sp = second ? s1 : s0;
+            const int Cp = second ? C1 : C0, cc = second ? c - C0 : c;
+            u0 = *reinterpret_cast<const f32x4*>(sp + ((size_t)b * L + tok) * Cp + cc);
+            u1 = *reinterpret_cast<const f32x4*>(sp + ((size_t)b * L + tok) * Cp + cc + 4);
+        }
     }
     if (do_gn) {      // statistics -> affine coefficients of this block's 32 channels, as the fused prologues do (conv.hip)
         const float* film = a.gn.film ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
@@ -730,9 +743,14 @@ size_t conv_x3_smem_bytes(const ConvArgs& a, ConvTile t) {
     return (size_t)1 << 30;
 }
 
-static hipError_t launch_x3_prep(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_x3_prep(const ConvArgs& a, hipStream_t s, const float* geglu_h = nullptr) {
     X3Prep p{};
     for (int k = 0; k < 4; ++k) { p.src[k] = a.src[k]; p.C[k] = a.C[k]; }
+    if (geglu_h) {
+        if (a.nmain != 1 || a.Cskip || a.gn.sums) return hipErrorInvalidValue;
+        p.src[0] = geglu_h;
+        p.geglu = 1;
+    }
     p.Cmain = a.Cmain; p.Cskip = a.Cskip; p.Lsrc = a.Lsrc; p.Lskip = a.Lskip; p.B = a.B;
     p.gn = a.gn;
     p.seg_src = a.seg_src;
@@ -793,9 +811,13 @@ hipError_t conv_x3_init_attrs() {
 }
 
 // tiles are encoded as ConvTile{MT, NT, NW = 48, KS, XM = 0}; the launch is the elementwise pass + the GEMM (KS K slices per tile)
-hipError_t launch_conv_x3(const ConvArgs& a, ConvTile t, hipStream_t s) {
+hipError_t launch_conv_x3(const ConvArgs& a, ConvTile t, hipStream_t s) { return launch_conv_x3_geglu(a, t, nullptr, s); }
+
+// ... with the input taken as GEGLU(h), h [B * rows][2 Cmain] (the elementwise pass applies it: no separate k_geglu launch, no
+// [rows][Cmain] round trip); h = nullptr: the plain form
+hipError_t launch_conv_x3_geglu(const ConvArgs& a, ConvTile t, const float* h, hipStream_t s) {
     if (!conv_x3_eligible(a) || !a.x3) return hipErrorInvalidValue;
-    hipError_t e = launch_x3_prep(a, s);
+    hipError_t e = launch_x3_prep(a, s, h);
     if (e != hipSuccess) return e;
 #define X3_L(M, N_) if (t.MT == M && t.NT == N_) return launch_x3_t<M, N_>(a, t.KS, s);
     X3_TILES(X3_L)

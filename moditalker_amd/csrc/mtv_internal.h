@@ -267,6 +267,7 @@ size_t conv_x3_scratch_bytes(int B, int Lsrc, int Cmain, int Lskip, int Cskip);
 size_t conv_x3_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t conv_x3_init_attrs();
 hipError_t launch_conv_x3(const ConvArgs& a, ConvTile t, hipStream_t s);
+hipError_t launch_conv_x3_geglu(const ConvArgs& a, ConvTile t, const float* h, hipStream_t s);
 hipError_t launch_split_w3(const float* W, void* W3, size_t plane_bytes, int row0, int rows, int ldw, hipStream_t s);
 bool conv_lin_eligible(const ConvArgs& a);
 size_t lin_smem_bytes(const ConvArgs& a);
