@@ -819,10 +819,17 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     for (auto& op : p->convs) {
         ConvArgs a = op->a;
         a.ddim = nullptr;       // the tuner times the conv itself, not the step hand-over
-        char key[160];
+        char key[176];
         snprintf(key, sizeof key, "B%d L%d/%d/%d N%d t%d C%d+%d gn%d f%d r%d s%d cm%d", a.B, a.Lout, a.Lsrc, a.Lskip, a.N, a.ntaps, a.Cmain, a.Cskip,
                  a.gn.sums ? 1 : 0, a.gn.film ? 1 : 0, a.res ? 1 : 0, a.nstat, a.out_cm);
         auto it = c->tune_cache.find(key);
+        // Two 1x1 convs can share a key and differ in whether the lean kernel (k_lin: identity rows, [N][K] weight copy) can run them.
+        // The entry of the one it can run must not be evicted (and re-timed in every process) by the other: that one has its own
+        // entry under "<key> x".
+        if (it != c->tune_cache.end() && it->second.NW == 64 && !conv_lin_eligible(a)) {
+            strncat(key, " x", sizeof key - strlen(key) - 1);
+            it = c->tune_cache.find(key);
+        }
         if (it != c->tune_cache.end()) {             // an entry read from MTV_TUNE_CACHE is only trusted if it is launchable
             const ConvTile& t = it->second;
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;

@@ -197,3 +197,38 @@ def test_autoencoder_state_dict_layout_matches_reference_manifest():
         ViTAutoencoder(4, BASE_AE_DDCONFIG).forward(torch.zeros(1))
     with pytest.raises(MtvError):                                   # off-GPU: loud, no CPU fallback
         ViTAutoencoder(4, dict(BASE_AE_DDCONFIG, resolution=64)).decode_from_sample(torch.zeros(1, 4, 8 * 8 + 2 * 16 * 8))
+
+
+def test_committed_tile_table_is_well_formed():
+    """moditalker_amd/csrc/tune_gfx950.txt (conv shape -> measured best tile, read at plan build): unique keys, five integers per
+    entry, every tile one that a launcher exists for -- and the one-clip R = 32 plan (the metric's workload) keeps the exact-f32
+    kernels: none of its shapes is on the split-bf16 pair (NW = 48)."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "moditalker_amd", "csrc", "tune_gfx950.txt")
+    x3_tiles = {(4, 2), (8, 2), (4, 4), (2, 2), (4, 1), (2, 1), (8, 1)}           # csrc/conv_x3.hip X3_TILES
+    seen, n48, twins = set(), 0, []
+    for line in open(path):
+        if line.startswith("#") or not line.strip():
+            continue
+        key, _, val = line.rstrip("\n").partition("|")
+        assert key not in seen, key
+        seen.add(key)
+        mt, nt, nw, ks, xm = (int(v) for v in val.split())
+        m = re.match(r"B(\d+) L(\d+)/(\d+)/(\d+) N(\d+) t(\d+) C(\d+)\+(\d+) ", key)
+        assert m, key
+        if key.endswith(" x"):            # the entry of a 1x1 conv k_lin cannot run, beside the one (same shape) it can
+            twins.append(key[:-2])
+            assert nw != 64, key
+        B, L, N, taps, Cm, Cs = int(m.group(1)), int(m.group(2)), int(m.group(5)), int(m.group(6)), int(m.group(7)), int(m.group(8))
+        if nw == 48:                      # k_x3_prep + k_conv_x3<MT, NT>, KS K slices of >= 6 chunks of 32 channels
+            n48 += 1
+            assert (mt, nt) in x3_tiles and ks in (1, 2, 4, 8) and xm == 0, line
+            assert 6 * ks <= taps * (Cm // 32) + Cs // 32 and Cm % 32 == 0 and Cs % 32 == 0 and N % 4 == 0 and N >= 64, line
+            assert B * L >= 1024 and not (B == 1 and L <= 2048), line
+        elif nw == 64:                    # k_lin<MT, NT, NWV>: 1x1 only
+            assert taps == 1 and mt in (1, 2) and nt in (1, 2, 4) and ks in (1, 2, 4), line
+        elif nw == 32:                    # k_conv_lds<WM, WN>
+            assert mt in (2, 4) and nt in (2, 4, 8) and ks == 1, line
+        else:                             # k_conv<MT, NT, NW>
+            assert mt in (1, 2, 4) and nt in (1, 2, 4) and nw in (1, 2, 4, 8, 16) and ks in (1, 2, 4, 8, 16) and xm in (0, 1), line
+    assert len(seen) >= 150 and n48 >= 20 and all(k in seen for k in twins)
