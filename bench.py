@@ -412,6 +412,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            # fp32 in, fp32 out, fp32-class products everywhere: v_mfma_f32_16x16x4_f32 (exact) except the QK^T of the 12 level-0 attention
+            # launches, taken as six bf16 partial products of a three-term split of q and k (24 mantissa bits, f32 accumulation) --
+            # same parity bars as the exact path (tests/test_gpu_parity.py: eps <= 2e-4, the 250-step sample <= 1e-3 vs the reference golden)
+            "precision_note": "fp32-class throughout; QK^T of the 2048-token attentions = 3-term bf16 split, 6 products (~2^-24 relative)",
             "data": "synthetic (random-init weights incl. zero-init tensors, U(-1,1) cond latents, N(0,1) noise)",
             "distributed": dist_info,
             "cpu_affinity": {k: v for k, v in affinity.items() if not k.startswith("_")},
