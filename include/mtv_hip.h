@@ -159,6 +159,13 @@ int mtv_debug_attention_b3(int mode);
  * instruction): 1 on, 0 off, -1 back to the build default / MTV_ATT_QB. */
 int mtv_debug_attention_qb(int mode);
 
+/* Which convolution kernels the levels of at most 128 tokens per clip run on in plans built after this call (batch <= 2):
+ * 1 = the K-sliced kernels of csrc/deep.hip (k_deep_conv: the consumers add the producers' partial slabs and compute the
+ * GroupNorm statistics themselves), 0 = k_conv everywhere, -1 = back to the default (on) / the MTV_DEEP environment variable.
+ * Replaces the same reference code either way: ResBlock convs and the attention blocks' qkv / proj_out at those levels
+ * (MToV/models/ddpm/unet.py:178-207, 234, 253).  The parity tests run both. */
+int mtv_debug_deep(int mode);
+
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
 int mtv_set_eager(mtv_ctx* ctx, int eager);
 

@@ -103,6 +103,7 @@ SYMBOLS = [
     ("mtv_debug_force_b3", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_attention_b3", C.c_int, [C.c_int]),
     ("mtv_debug_attention_qb", C.c_int, [C.c_int]),
+    ("mtv_debug_deep", C.c_int, [C.c_int]),
     ("mtv_ae_create", C.c_int, [C.POINTER(MtvAeConfig), C.POINTER(_P)]),
     ("mtv_ae_destroy", C.c_int, [_P]),
     ("mtv_ae_set_rotary", C.c_int, [_P, _P, _P]),

@@ -372,7 +372,7 @@ hipError_t attn_b3_init_attrs() {
 // shape is chosen here (same policy as launch_attention: 64-query workgroups from 128 workgroups up, 32-query ones for
 // uneven segments that would leave at most one workgroup per CU, 16-query x 4 key parts for short segments).
 bool attn_b3_eligible(const AttnArgs& a) {
-    if (a.kv || a.kmask || a.seg_uniform || a.H < 1 || a.C % a.H) return false;
+    if (a.kv || a.kmask || a.seg_uniform || a.H < 1 || a.C % a.H || a.qkv_ks > 1) return false;     // (slab-summed qkv of the deep levels: k_attention only)
     const int d = a.C / a.H;
     return d == 16 || d == 32 || d == 64;
 }

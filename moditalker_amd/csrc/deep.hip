@@ -1,0 +1,710 @@
+// Convolutions of the DEEP levels of the tri-plane UNet (<= 128 tokens per clip: levels 2 and 3 of the base model) for gfx950.
+//
+// Replaces, at those levels: ResBlock in_layers / out_layers / skip_connection (MToV/models/ddpm/unet.py:131-167, 178-207) and
+// the attention blocks' qkv / proj_out conv1d (unet.py:234, 242, 251, 253) with the GroupNorm in front of them
+// (diffusionmodules.py:156-173).  Same arithmetic as conv.hip (exact f32 on v_mfma_f32_16x16x4_f32), different dataflow:
+//
+// At <= 128 tokens a conv is a weight stream (9.4-18.9 MB for 0.15-1.2 GFLOP) and a launch of k_conv spends most of its
+// 13-26 us on dependent round trips: GroupNorm statistics from the producers' atomics, gather tables, a ring fill that only
+// starts after them, and a three-hop cross-workgroup split-K hand-off (profiles/r03_conv_phase_stamps.txt).  Here
+//   * the K dimension is cut into KS channel SLICES (all taps of CSm input channels each) and every slice writes its
+//     partial result to its own slab -- nobody finishes the sum inside the launch: no slab round trip, no ticket;
+//   * every CONSUMER adds the slabs of the channel slice it reads (slab order: run-to-run bit-equal) and computes the
+//     GroupNorm statistics of that slice itself -- a workgroup stages ALL tokens of its channel slice in LDS, so the
+//     statistics need no atomics and no table, and GroupNorm / FiLM / SiLU are applied ONCE per element on the way in
+//     (k_conv re-applies them per tap and per column tile);
+//   * a workgroup's weights are one contiguous run of the repacked matrix (k_deep_repack) that depends on nothing: the four
+//     MFMA waves request them at kernel entry, straight into registers (1 KB per wave instruction, non-temporal), while the
+//     four STAGER waves fetch, sum, normalise and park the activation slice -- the two streams have separate vmcnt queues
+//     (a wave's loads return in order: one wave doing both would wait for its HBM-cold weights before it could touch the
+//     L2-warm activations).
+//
+// Workgroup = (clip, row group, K slice, column tile of 16 NT channels), 512 threads.  Row group: all planes (nrg = 1) or
+// {xy} | {yt, xt} (nrg = 2; GroupNorm statistics are per plane, 3x3 taps never cross planes) -- RT row tiles of 16 tokens.
+// MFMA operand maps as in conv.hip: A lane (i, q) holds x[row i][c0 + 4q .. + 3] (one ds_read_b128 from the staged slice, row
+// chosen by the tap through a per-workgroup row table, zero padding = a zero row), B lane (j, q) holds
+// W[c0 + 4q .. + 3][n0 + j] (one 16-byte global load, lane-linear in the repacked matrix), MFMA step s consumes component s.
+#include <cstdio>
+#include <cstdlib>
+
+#include "mtv_internal.h"
+
+namespace mtv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int DEEP_PAD = 8;          // LDS row stride = slice channels + 8 floats: the 16 lanes of a ds_read_b128 lane group hit
+                                     // 16 distinct bank quads (stride/4 = 2 mod 16 over rows i, + q; MI355X_MICROARCH.md LDS table)
+constexpr int DEEP_NTH = 512;
+constexpr int DEEP_MAX_NG = 16;      // GroupNorm groups per channel slice
+
+__device__ __forceinline__ float deep_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ int deep_usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// sum of the KSI slabs of one 16-byte quad, slab order
+template <int KSI>
+__device__ __forceinline__ void slab_issue(const float* p, unsigned stride, f32x4 (&v)[KSI]) {
+#pragma unroll
+    for (int k = 0; k < KSI; ++k) v[k] = *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
+}
+template <int KSI>
+__device__ __forceinline__ f32x4 slab_fold(const f32x4 (&v)[KSI]) {
+    f32x4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < KSI; ++k) s += v[k];
+    return s;
+}
+__device__ __forceinline__ f32x4 slab_sum_rt(const float* p, unsigned stride, int ks) {     // run-time slab count (epilogue residual)
+    f32x4 s = *reinterpret_cast<const f32x4*>(p);
+    for (int k = 1; k < ks; ++k) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
+    return s;
+}
+
+// Staging of a channel slice (nrows rows x 4 QW channels) of a slab tensor, all 512 threads: thread (rl, qd) takes the quad
+// column qd of rows rl, rl + RP, ... (RP = 512 / QW), NLD = 16 sixteen-byte loads in flight per pass (U rows x KSI slabs).
+// The FIRST pass is split into issue / consume so that the caller can request its weights in between: a wave's loads return
+// in order, so the (L2 / Infinity-Cache warm) activations must be requested BEFORE the HBM-cold weights.
+template <int KSI>
+struct StageRegs {
+    static constexpr int U = 16 / KSI;
+    f32x4 v[U][KSI];
+};
+template <int KSI>
+__device__ __forceinline__ void stage_issue(StageRegs<KSI>& sr, const float* colp, unsigned slab_stride, int C, int nrows, int row0, int RP) {
+    const int rbase = row0 - (row0 % RP);                // (row0 = this thread's row lane + a multiple of RP)
+#pragma unroll
+    for (int u = 0; u < StageRegs<KSI>::U; ++u) {
+        if (rbase + u * RP >= nrows) break;              // wave-uniform: nobody has a row in this slot -- no loads at all
+        const int row = row0 + u * RP;
+        const float* p = colp + (size_t)(row < nrows ? row : 0) * C;
+#pragma unroll
+        for (int k = 0; k < KSI; ++k) sr.v[u][k] = *reinterpret_cast<const f32x4*>(p + (size_t)k * slab_stride);
+    }
+}
+template <int KSI, bool STATS>
+__device__ __forceinline__ void stage_consume(const StageRegs<KSI>& sr, int nrows, int row0, int RP, float* ldsq, int lstride, int tok0, int b1s, int b2s,
+                                              double (&acc)[6]) {
+#pragma unroll
+    for (int u = 0; u < StageRegs<KSI>::U; ++u) {
+        const int row = row0 + u * RP;
+        if (row < nrows) {
+            f32x4 x = sr.v[u][0];
+#pragma unroll
+            for (int k = 1; k < KSI; ++k) x += sr.v[u][k];           // slab order
+            *reinterpret_cast<f32x4*>(ldsq + row * lstride) = x;
+            if constexpr (STATS) {
+                const int tk = tok0 + row;
+                const double s = ((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3]);
+                const double ss = ((double)x[0] * x[0] + (double)x[1] * x[1]) + ((double)x[2] * x[2] + (double)x[3] * x[3]);
+                const bool p2 = tk >= b2s, p1 = tk >= b1s && !p2;
+                acc[0] += (!p1 && !p2) ? s : 0.0;
+                acc[1] += (!p1 && !p2) ? ss : 0.0;
+                acc[2] += p1 ? s : 0.0;
+                acc[3] += p1 ? ss : 0.0;
+                acc[4] += p2 ? s : 0.0;
+                acc[5] += p2 ? ss : 0.0;
+            }
+        }
+    }
+}
+// one slice: first pass issue -> mid() -> consume -> further passes
+template <int KSI, bool STATS, class Mid>
+__device__ __forceinline__ void stage_slice(const float* base, unsigned slab_stride, int C, int nrows, int qw_shift, int tid, float* lds, int lstride, int tok0,
+                                            int b1s, int b2s, double (&acc)[6], Mid mid) {
+    const int QW = 1 << qw_shift, RP = DEEP_NTH >> qw_shift;
+    const int qd = tid & (QW - 1), rl = tid >> qw_shift;
+    const float* colp = base + 4 * qd;
+    float* ldsq = lds + 4 * qd;
+    StageRegs<KSI> sr;
+    stage_issue<KSI>(sr, colp, slab_stride, C, nrows, rl, RP);
+    mid();
+    stage_consume<KSI, STATS>(sr, nrows, rl, RP, ldsq, lstride, tok0, b1s, b2s, acc);
+    for (int row0 = rl + RP * StageRegs<KSI>::U; row0 < nrows; row0 += RP * StageRegs<KSI>::U) {
+        stage_issue<KSI>(sr, colp, slab_stride, C, nrows, row0, RP);
+        stage_consume<KSI, STATS>(sr, nrows, row0, RP, ldsq, lstride, tok0, b1s, b2s, acc);
+    }
+}
+template <bool STATS, class Mid>
+__device__ __forceinline__ void stage_slice_ks(const DeepSrc& src, const float* base, int nrows, int qw_shift, int tid, float* lds, int lstride, int tok0,
+                                               int b1s, int b2s, double (&acc)[6], Mid mid) {
+    switch (src.ks) {
+        case 1: stage_slice<1, STATS>(base, src.slab_stride, src.C, nrows, qw_shift, tid, lds, lstride, tok0, b1s, b2s, acc, mid); break;
+        case 2: stage_slice<2, STATS>(base, src.slab_stride, src.C, nrows, qw_shift, tid, lds, lstride, tok0, b1s, b2s, acc, mid); break;
+        case 4: stage_slice<4, STATS>(base, src.slab_stride, src.C, nrows, qw_shift, tid, lds, lstride, tok0, b1s, b2s, acc, mid); break;
+        default: stage_slice<8, STATS>(base, src.slab_stride, src.C, nrows, qw_shift, tid, lds, lstride, tok0, b1s, b2s, acc, mid); break;
+    }
+}
+
+}  // namespace
+
+#ifdef MTV_DEEP_STAMP   // s_memtime of lane 0 of waves 0 and 4 of workgroups 0 and gridDim / 2: [wg][wave][16 slots]
+#define DEEP_STAMP(k) do { if (a.dbg && (tid == 0 || tid == 256) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) \
+                               a.dbg[(blockIdx.x ? 32 : 0) + (tid ? 16 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DEEP_STAMP(k) do { } while (0)
+#endif
+
+template <int RT, int NT>
+__global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
+    const int tid = threadIdx.x;
+    DEEP_STAMP(0);
+    touch_kernargs<(int)sizeof(DeepArgs)>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * RT;
+    constexpr int G = RT * NT >= 24 ? 2 : 3;           // chunks per weight group; two groups in flight per wave
+    const int lane = tid & 63;
+    const int wave = deep_usgpr(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    // ---- workgroup -> (column tile j, clip b, row group rg, K slice s).  Consecutive workgroup ids (round-robin over the 8
+    // XCDs) share the column tile and differ in (b, rg, s): all column tiles of one (rg, s) -- which read the SAME activation
+    // slice -- meet on one XCD when nslots is a multiple of 8 (speed only).
+    const int blk = deep_usgpr((int)blockIdx.x);
+    const int j = deep_usgpr(FDiv{a.inv_nslots}(blk, a.nslots));
+    const int slot = blk - j * a.nslots;
+    const int s = slot & (a.KS - 1);
+    const int rgb = slot >> a.ks_shift;
+    const int rg = rgb & (a.nrg - 1);
+    const int b = rgb >> (a.nrg - 1);
+    // geometry: output level and the level of the tapped source
+    const int r = a.r, t = a.t;
+    const int b1 = r * r, b2 = b1 + t * r, L = b2 + t * r;
+    const int rs = a.up_main ? r >> 1 : r, ts = a.up_main ? t >> 1 : t;
+    const int b1s = rs * rs, b2s = b1s + ts * rs, Ls = b2s + ts * rs;
+    const int rg_tok0 = (a.nrg == 2 && rg) ? b1 : 0;
+    const int rg_ntok = a.nrg == 2 ? (rg ? L - b1 : b1) : L;
+    const int src_tok0 = (a.nrg == 2 && rg) ? b1s : 0;
+    const int src_ntok = a.nrg == 2 ? (rg ? Ls - b1s : b1s) : Ls;
+    const int SM = a.CSm + DEEP_PAD, SS = a.CSs + DEEP_PAD;
+    const int zoff_main = a.src_rows_max * SM;         // float offset of the zero row of the main slice
+    float* const lmain = smem;
+    float* const lskip = smem + a.lds_skip;
+    int* const idx = reinterpret_cast<int*>(smem + a.lds_idx);       // [ntaps][ROWS] float offsets into lmain | [ROWS] into lskip
+    double* const sdp = reinterpret_cast<double*>(smem + a.lds_stat);     // [3 planes][DEEP_MAX_NG][2]: (sum, sum of squares) of the slice
+    const int nch = a.nch;
+    DEEP_STAMP(1);
+
+    // =========================================================================================================== phase 0
+    // request order per wave: activation slice (first pass) -> GroupNorm vectors -> weights; then the row table while they fly
+    // Weights through a buffer descriptor over this workgroup's run of the repacked matrix: chunk indices past the end of the
+    // slice read as ZERO without a branch, so every wave executes the same straight-line request sequence (exact vmcnt).
+    f32x4 bq[2][G][NT];
+    const int n_it = (nch + 7) >> 3;                   // iterations of the chunk loop: wave w takes chunks w, w + 8, ...
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.W + ((size_t)(j * a.KS + s) * nch) * (NT * 256)), 0, nch * NT * 1024, 0x00020000);
+    auto wload = [&](f32x4 (&dst)[G][NT], int k0) {     // iterations k0 .. k0 + G - 1
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int soff = (wave + 8 * (k0 + g)) * (NT * 1024);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                dst[g][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + nt * 1024, soff, 2));   // aux 2 = nt
+        }
+    };
+    const int qw_shift = a.cpt_shift + 2;              // log2(CSm / 4)
+    const int QWm = 1 << qw_shift;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    // (raw registers: ANY use of a loaded value makes the wave wait for every OLDER load too -- `1 + scale` is formed in phase 1)
+    f32x4 ga, be, fsc, sh;
+    const int cm0 = s * a.CSm;                         // first channel of this slice on the concatenated channel axis
+    auto mid = [&]() {
+        DEEP_STAMP(12);
+        {   // GroupNorm / FiLM vectors of this thread's channel quad (the same in every row it stages).  UNCONDITIONAL loads
+            // into their final registers: the launcher points absent vectors at a zero buffer -- a conditional load here ends
+            // in a register copy at the join, and a copy of a loaded value waits for every older load (the whole slice)
+            const int cg = cm0 + 4 * (tid & (QWm - 1));
+            const float* fm = a.film + (size_t)b * a.film_stride;
+            ga = *reinterpret_cast<const f32x4*>(a.gamma + cg);
+            be = *reinterpret_cast<const f32x4*>(a.beta + cg);
+            fsc = *reinterpret_cast<const f32x4*>(fm + cg);
+            sh = *reinterpret_cast<const f32x4*>(fm + a.Cmain + cg);
+        }
+        wload(bq[0], 0);
+        wload(bq[1], G);
+        DEEP_STAMP(13);
+        // row table, zero rows, statistics slots: LDS work under the loads
+        for (int e = tid; e < a.ntaps * ROWS; e += DEEP_NTH) {
+            const int tap = e / ROWS, ri = e - tap * ROWS;
+            const int tok = rg_tok0 + ri;
+            int row = -1;
+            if (ri < rg_ntok) {
+                if (a.ntaps == 9) {
+                    const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+                    const int g = geo_source_t<FDiv>(FDiv{a.inv_r}, r, t, tok, ky, tap - 3 * ky, a.up_main != 0);
+                    row = g < 0 ? -1 : (g & 0x0FFFFFFF) - src_tok0;
+                } else if (a.up_main) {
+                    row = (geo_source_t<FDiv>(FDiv{a.inv_r}, r, t, tok, 1, 1, true) & 0x0FFFFFFF) - src_tok0;
+                } else {
+                    row = tok - src_tok0;
+                }
+            }
+            idx[e] = row < 0 ? zoff_main : row * SM;
+        }
+        for (int e = tid; e < ROWS; e += DEEP_NTH) idx[a.ntaps * ROWS + e] = e < rg_ntok ? e * SS : ROWS * SS;
+        for (int e = tid; e < a.CSm; e += DEEP_NTH) lmain[zoff_main + e] = 0.f;
+        if (a.Cskip)
+            for (int e = tid; e < a.CSs; e += DEEP_NTH) lskip[ROWS * SS + e] = 0.f;
+        for (int e = tid; e < 3 * DEEP_MAX_NG * 2; e += DEEP_NTH) sdp[e] = 0.0;
+        DEEP_STAMP(8);
+        __syncthreads();                                              // (statistics slots are zero before anybody adds to them)
+        DEEP_STAMP(14);
+    };
+    {
+        const int part = (a.main[1].p && cm0 >= a.main[0].C) ? 1 : 0;
+        const DeepSrc& src = a.main[part];
+        const float* base = src.p + ((size_t)b * a.Lsrc + src_tok0) * src.C + (cm0 - (part ? a.main[0].C : 0));
+        if (a.gn) stage_slice_ks<true>(src, base, src_ntok, qw_shift, tid, lmain, SM, src_tok0, b1s, b2s, acc, mid);
+        else stage_slice_ks<false>(src, base, src_ntok, qw_shift, tid, lmain, SM, src_tok0, b1s, b2s, acc, mid);
+    }
+    DEEP_STAMP(9);
+    if (a.Cskip) {
+        // (requested behind the weights, which the MFMA loop needs anyway: the slice arrives with them)
+        const int cs0 = s * a.CSs;
+        const int sp = (a.skip[1].p && cs0 >= a.skip[0].C) ? 1 : 0;
+        const DeepSrc& ssrc = a.skip[sp];
+        const float* sbase = ssrc.p + ((size_t)b * a.Lout + rg_tok0) * ssrc.C + (cs0 - (sp ? a.skip[0].C : 0));
+        int sq_shift = 0;
+        while ((4 << sq_shift) < a.CSs) ++sq_shift;                  // log2(CSs / 4)
+        double dummy[6];
+        stage_slice_ks<false>(ssrc, sbase, rg_ntok, sq_shift, tid, lskip, SS, 0, 0, 0, dummy, []() {});
+    }
+    DEEP_STAMP(10);
+    const int qdm = tid & (QWm - 1);
+    const int gi = (4 * qdm) / (a.gn ? a.gs : 4);                      // GroupNorm group of this thread's quad, within the slice
+    if (a.gn) {
+        // per-thread partial sums -> the slice's (plane, group) slots.  Quads of one group sit in adjacent lanes: fold them first
+        // (2 DPP-free shuffles would cost more than the contention they save at gs <= 16: plain LDS fp64 atomics)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (acc[2 * p + 1] != 0.0) {
+                atomicAdd(&sdp[(p * DEEP_MAX_NG + gi) * 2], acc[2 * p]);
+                atomicAdd(&sdp[(p * DEEP_MAX_NG + gi) * 2 + 1], acc[2 * p + 1]);
+            }
+    }
+    DEEP_STAMP(2);
+    __syncthreads();
+    DEEP_STAMP(3);
+    // =========================================================================================================== phase 1
+    if (a.gn) {
+        // y = x * A + B with A = rstd gamma (1 + film_scale), B = (beta - rstd gamma mean)(1 + film_scale) + film_shift, then SiLU:
+        // applied ONCE per element, in place in LDS (this thread's quad column: coefficients per plane in registers)
+        const int RP = DEEP_NTH >> qw_shift;
+        const int rl = tid >> qw_shift;
+        f32x4 cA[3], cB[3];
+        double sx[3], sy[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            sx[p] = sdp[(p * DEEP_MAX_NG + gi) * 2];
+            sy[p] = sdp[(p * DEEP_MAX_NG + gi) * 2 + 1];
+        }
+        if (a.whole) {
+            sx[0] = sx[1] = sx[2] = (sx[0] + sx[1]) + sx[2];
+            sy[0] = sy[1] = sy[2] = (sy[0] + sy[1]) + sy[2];
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const double inv_n = a.whole ? a.inv_n[3] : a.inv_n[p];
+            const double mean = sx[p] * inv_n;
+            double var = sy[p] * inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const float mu = (float)mean, rstd = 1.0f / sqrtf((float)var + 1e-5f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float sc = rstd * ga[k];
+                const float bi = be[k] - sc * mu;
+                const float s1 = 1.0f + fsc[k];
+                cA[p][k] = sc * s1;
+                cB[p][k] = fmaf(bi, s1, sh[k]);
+            }
+        }
+        const bool act = a.act != 0;
+        for (int row = rl; row < src_ntok; row += RP) {
+            const int tk = src_tok0 + row;
+            const bool p2 = tk >= b2s, p1 = tk >= b1s && !p2;
+            const f32x4 A = p2 ? cA[2] : (p1 ? cA[1] : cA[0]), Bc = p2 ? cB[2] : (p1 ? cB[1] : cB[0]);
+            f32x4* cell = reinterpret_cast<f32x4*>(lmain + row * SM + 4 * qdm);
+            f32x4 v = *cell;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float y = fmaf(v[k], A[k], Bc[k]);
+                v[k] = act ? deep_silu(y) : y;
+            }
+            *cell = v;
+        }
+    }
+    __syncthreads();
+    DEEP_STAMP(4);
+    // =========================================================================================================== phase 2
+    // epilogue operands of K slice 0 (bias, residual: they depend on nothing computed here) are requested now by every
+    // thread for its first output quad; they land under the MFMA loop
+    constexpr int QPR = 4 * NT, QUADS = ROWS * QPR;
+    const int n0 = j * (16 * NT);
+    f32x4 pre = {0.f, 0.f, 0.f, 0.f};
+    auto epi_operands = [&](int e) -> f32x4 {
+        const int rr = e / QPR, cq = e - rr * QPR;
+        const int tok = rg_tok0 + rr, n = n0 + 4 * cq;
+        f32x4 o = *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (a.bias2) o += *reinterpret_cast<const f32x4*>(a.bias2 + n);
+        if (a.bias_b) o += *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + n);
+        if (a.res.p) {
+            const int rtok = a.up_res ? (geo_source_t<FDiv>(FDiv{a.inv_r}, r, t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
+            o += slab_sum_rt(a.res.p + ((size_t)b * a.Lres + rtok) * a.res.C + n, a.res.slab_stride, a.res.ks);
+        }
+        return o;
+    };
+    const bool pre_ok = s == 0 && tid < QUADS && tid / QPR < rg_ntok;
+    if (pre_ok) pre = epi_operands(tid);
+
+    f32x4 accm[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accm[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        // Chunk loop, software pipelined: the A fragments of iteration k + 1 (row-table entries, then one ds_read_b128 per row
+        // tile) are requested before the MFMAs of iteration k; the weights of iteration k + 2G replace those of k as soon as
+        // its group is done.  Iterations past this wave's last chunk run on zero weights (at most one, in the last round).
+        const int cpt_mask = (1 << a.cpt_shift) - 1;
+        auto loadA = [&](int k, f32x4 (&av)[RT]) {
+            int c = wave + 8 * k;
+            c = c < nch ? c : nch - 1;                                 // (clamped: a valid address; its weights are zero)
+            const bool sk = c >= a.nmain_ch;
+            const int tap = sk ? a.ntaps : c >> a.cpt_shift;
+            const int cc = sk ? c - a.nmain_ch : c & cpt_mask;
+            const float* ab = (sk ? lskip : lmain) + cc * 16 + 4 * q;
+            const int* ip = idx + tap * ROWS + i;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(ab + ip[16 * rt]);
+        };
+        auto mma = [&](const f32x4 (&av)[RT], const f32x4 (&w)[NT]) {
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        accm[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sI], w[nt][sI], accm[rt][nt], 0, 0, 0);
+        };
+        constexpr bool PIPE = RT * NT < 24;                             // (the largest tile has no registers for a second fragment set
+                                                                       //  -- and 96 MFMAs per chunk to hide one LDS round trip under)
+        f32x4 avA[RT], avB[PIPE ? RT : 1];
+        // one iteration: `par` = which fragment set holds iteration kk's rows (PIPE); the other one receives iteration kk + 1's
+        auto step = [&](int kk, int par, const f32x4 (&w)[NT]) {
+            if constexpr (PIPE) {
+                if (par) { loadA(kk + 1, avA); mma(avB, w); }
+                else { loadA(kk + 1, avB); mma(avA, w); }
+            } else {
+                loadA(kk, avA);
+                mma(avA, w);
+            }
+        };
+        if constexpr (PIPE) loadA(0, avA);
+        int k = 0;
+        for (; k + 2 * G <= n_it; k += 2 * G) {                         // (2G = 6 iterations per round: fragment parity = g & 1, then (G + g) & 1)
+#pragma unroll
+            for (int g = 0; g < G; ++g) step(k + g, g & 1, bq[0][g]);
+            wload(bq[0], k + 2 * G);
+#pragma unroll
+            for (int g = 0; g < G; ++g) step(k + G + g, (G + g) & 1, bq[1][g]);
+            wload(bq[1], k + 3 * G);
+        }
+        // tail: n_it - k in 0 .. 2G - 1 iterations, weights already requested; uniform guards, no memory requests inside
+        const int rem = n_it - k;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (g < rem) step(k + g, g & 1, bq[0][g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (G + g < rem) step(k + G + g, (G + g) & 1, bq[1][g]);
+    }
+    DEEP_STAMP(5);
+    __syncthreads();
+    DEEP_STAMP(6);
+    // =========================================================================================================== phase 3
+    // the eight partial tiles (one per wave) -> LDS as (row, col) images, summed in wave order by all threads; tiles too large
+    // for eight images at once fold waves 4-7 into waves 0-3 first
+    constexpr int LDR = 16 * NT + 4;
+    constexpr bool ONE_ROUND = 8 * ROWS * LDR * 4 <= 96 * 1024;
+    constexpr int NIMG = ONE_ROUND ? 8 : 4;
+    float* const red = smem + a.lds_red;
+    auto park = [&](int slot_w) {
+        float* my = red + (size_t)slot_w * ROWS * LDR + (4 * q) * LDR + i;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) my[(16 * rt + rr) * LDR + 16 * nt] = accm[rt][nt][rr];
+    };
+    if constexpr (ONE_ROUND) {
+        park(wave);
+    } else {
+        if (wave >= 4) park(wave - 4);
+        __syncthreads();
+        if (wave < 4) {
+            const float* my = red + (size_t)wave * ROWS * LDR + (4 * q) * LDR + i;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) accm[rt][nt][rr] += my[(16 * rt + rr) * LDR + 16 * nt];
+            park(wave);
+        }
+    }
+    __syncthreads();
+    float* const outp = a.out + (size_t)s * a.out_slab_stride;
+    for (int e = tid; e < QUADS; e += DEEP_NTH) {
+        const int rr = e / QPR, cq = e - rr * QPR;
+        if (rr >= rg_ntok) continue;
+        const float* rp = red + rr * LDR + 4 * cq;
+        f32x4 v = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+        for (int w = 1; w < NIMG; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
+        if (s == 0) v += (e == tid && pre_ok) ? pre : epi_operands(e);
+        *reinterpret_cast<f32x4*>(outp + ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq) = v;
+    }
+    DEEP_STAMP(7);
+}
+
+// legacy conv matrix [krow = tap * Cmain + c | ntaps * Cmain + c_skip][ldw] -> [column tile][K slice][chunk][NT][lane][4]
+__global__ void k_deep_repack(const float* W, int ldw, float* dst, DeepArgs a, int NT, long total) {
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int e = (int)(id & 3), lane = (int)((id >> 2) & 63);
+    long rest = id >> 8;
+    const int nt = (int)(rest % NT);
+    rest /= NT;
+    const int c = (int)(rest % a.nch);
+    rest /= a.nch;
+    const int s = (int)(rest % a.KS), j = (int)(rest / a.KS);
+    const int jj = lane & 15, q = lane >> 4;
+    int krow;
+    if (c < a.nmain_ch) {
+        const int tap = c >> a.cpt_shift, cc = c & ((1 << a.cpt_shift) - 1);
+        krow = tap * a.Cmain + s * a.CSm + cc * 16 + 4 * q + e;
+    } else {
+        krow = a.ntaps * a.Cmain + s * a.CSs + (c - a.nmain_ch) * 16 + 4 * q + e;
+    }
+    dst[id] = W[(size_t)krow * ldw + (j * NT + nt) * 16 + jj];
+}
+
+// slabs -> plain tensor (+ GroupNorm statistics for legacy consumers, conv.hip / k_pool_down).  Grid: (channel blocks of 64,
+// token blocks of 8, clips) -- wide on purpose: the pass is a latency chain (slab loads -> sum -> store), so it wants every CU
+// to hold a few quads, not a few CUs to hold everything.  64 channels x 8 tokens = 128 quads per workgroup of 128 threads.
+__global__ __launch_bounds__(128) void k_deep_finalize(const DeepFinArgs a) {
+    touch_kernargs<(int)sizeof(DeepFinArgs)>();
+    __shared__ double sdp[2][96][2];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, tok = blockIdx.y * 8 + (tid >> 4), ch = blockIdx.x * 64 + 4 * (tid & 15);
+    const int C = a.src.C;
+    const bool live = tok < a.L && ch < C;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const size_t off = ((size_t)b * a.L + tok) * C + ch;
+        const float* p = a.src.p + off;
+        f32x4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(p + (size_t)(k < a.src.ks ? k : 0) * a.src.slab_stride);   // all in flight
+        v = t[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < a.src.ks) v += t[k];                       // slab order
+        *reinterpret_cast<f32x4*>(a.out + off) = v;
+    }
+    if (!a.nstat) return;
+    for (int e = tid; e < a.nstat * 96 * 2; e += 128) (&sdp[0][0][0])[e] = 0.0;
+    __syncthreads();
+    if (live) {
+        const int sg = tok >= a.seg.b2 ? 2 : (tok >= a.seg.b1 ? 1 : 0);
+        for (int t = 0; t < a.nstat; ++t) {
+            const int gs = a.stat[t].gs;
+            if ((gs & 3) == 0) {
+                const int g = (a.stat[t].coff + ch) / gs;
+                atomicAdd(&sdp[t][sg * 32 + g][0], ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]));
+                atomicAdd(&sdp[t][sg * 32 + g][1], ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int g = (a.stat[t].coff + ch + k) / gs;
+                    atomicAdd(&sdp[t][sg * 32 + g][0], (double)v[k]);
+                    atomicAdd(&sdp[t][sg * 32 + g][1], (double)v[k] * v[k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < a.nstat * 96; e += 128) {
+        const int t = e / 96, r2 = e - t * 96;
+        const double sx = sdp[t][r2][0], sy = sdp[t][r2][1];
+        if (sy != 0.0) {
+            double* dst = a.stat[t].sums + (size_t)((blockIdx.x + blockIdx.y) & (STAT_COPIES - 1)) * a.stat_cstride + ((size_t)b * 96 + r2) * 2;
+            atomicAdd(dst, sx);
+            atomicAdd(dst + 1, sy);
+        }
+    }
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+size_t deep_weight_floats(const DeepArgs& a, int NT) {
+    (void)NT;
+    return (size_t)a.N * ((size_t)a.ntaps * a.Cmain + a.Cskip);
+}
+
+static int deep_rows(const DeepArgs& a, int* src_rows) {     // rows of the largest row group: output, tapped source
+    const int b1 = a.r * a.r, L = b1 + 2 * a.t * a.r;
+    const int rs = a.up_main ? a.r >> 1 : a.r, ts = a.up_main ? a.t >> 1 : a.t;
+    const int b1s = rs * rs, Ls = b1s + 2 * ts * rs;
+    if (a.nrg == 2) {
+        *src_rows = b1s > Ls - b1s ? b1s : Ls - b1s;
+        return b1 > L - b1 ? b1 : L - b1;
+    }
+    *src_rows = Ls;
+    return L;
+}
+
+bool deep_tile_for(const DeepArgs& a, DeepTile* t) {
+    int srows = 0;
+    const int rows = deep_rows(a, &srows);
+    int RT = (rows + 15) / 16;
+    RT = RT <= 1 ? 1 : (RT <= 2 ? 2 : (RT <= 4 ? 4 : (RT <= 8 ? 8 : 0)));
+    if (!RT) return false;
+    const int NT = (a.N % 48 == 0 && a.N >= 768) ? 3 : 1;
+    if (a.N % (16 * NT)) return false;
+    t->RT = RT;
+    t->NT = NT;
+    return true;
+}
+
+static size_t deep_layout(DeepArgs& a, DeepTile t);
+size_t deep_smem_bytes(const DeepArgs& a0, DeepTile t) {
+    DeepArgs a = a0;
+    return deep_layout(a, t);
+}
+static size_t deep_layout(DeepArgs& a, DeepTile t) {
+    int srows = 0;
+    (void)deep_rows(a, &srows);
+    const int ROWS = 16 * t.RT;
+    a.src_rows_max = srows;
+    const int SM = a.CSm + DEEP_PAD, SS = a.CSs + DEEP_PAD;
+    int off = (srows + 1) * SM;
+    a.lds_skip = off;
+    if (a.Cskip) off += (ROWS + 1) * SS;
+    a.lds_idx = off;
+    off += (a.ntaps + 1) * ROWS;
+    off = (off + 3) & ~3;
+    a.lds_stat = off;
+    off += (3 * DEEP_MAX_NG * 2) * 2;                                  // (sum, sum of squares) per (plane, group): doubles
+    a.lds_red = 0;                                                     // the reduction scratch reuses the staged slices
+    const int LDR = 16 * t.NT + 4;
+    const int red = (8 * ROWS * LDR * 4 <= 96 * 1024 ? 8 : 4) * ROWS * LDR;
+    return (size_t)(off > red ? off : red) * 4;
+}
+
+// Slicing of one conv of the deep levels: row groups, column tile, K slices.  `a` arrives with sources, channel counts, geometry and
+// GroupNorm flags set; on success nrg / KS / CSm / CSs / tiles_n are filled in.  K slices: the most that keep the grid at <= 256
+// workgroups (one per CU: every CU streams its share of the weights), within what the kernel supports -- power-of-two slices of
+// 16 ... 256 channels that hold whole GroupNorm groups and do not straddle the parts of a channel concatenation.
+bool deep_configure(DeepArgs& a, DeepTile* t) {
+    if (a.B < 1 || a.Lout < 1 || a.Lout > 128 || (a.N & 15) || (a.Cmain & 15) || (a.Cskip & 15)) return false;
+    if (a.ntaps != 9 && a.ntaps != 1) return false;
+    a.nrg = (a.Lout > 64 && !(a.gn && a.whole)) ? 2 : 1;
+    if (!deep_tile_for(a, t)) return false;
+    a.tiles_n = a.N / (16 * t->NT);
+    const int C0m = a.main[1].p ? a.main[0].C : 0, C0s = a.skip[1].p ? a.skip[0].C : 0;
+    int best = 0;
+    for (int KS = 1; KS <= 8; KS *= 2) {
+        if (a.Cmain % KS) continue;
+        const int CSm = a.Cmain / KS, CSs = a.Cskip / KS;
+        if (CSm < 16 || CSm > 256 || (CSm & (CSm - 1)) || (C0m && C0m % CSm)) continue;
+        if (a.gn && ((a.gs & 3) || (a.gs & (a.gs - 1)) || CSm % a.gs || CSm / a.gs > DEEP_MAX_NG)) continue;
+        if (a.Cskip && (a.Cskip % KS || CSs < 16 || CSs > 256 || (CSs & (CSs - 1)) || (C0s && C0s % CSs))) continue;
+        DeepArgs probe = a;
+        probe.KS = KS; probe.CSm = CSm; probe.CSs = CSs;
+        probe.nmain_ch = 0;
+        if (deep_smem_bytes(probe, *t) > 160 * 1024) continue;
+        if (!best || (long)a.B * a.nrg * a.tiles_n * KS <= 256) best = KS;
+    }
+    if (!best) return false;
+    a.KS = best;
+    a.CSm = a.Cmain / best;
+    a.CSs = a.Cskip / best;
+    for (const DeepSrc* sp : {&a.main[0], &a.main[1], &a.skip[0], &a.skip[1], &a.res})
+        if (sp->p && !(sp->ks == 1 || sp->ks == 2 || sp->ks == 4 || sp->ks == 8)) return false;
+    return true;
+}
+
+template <int RT, int NT>
+static hipError_t deep_launch_t(const DeepArgs& a, size_t smem, hipStream_t s) {
+    hipLaunchKernelGGL((k_deep_conv<RT, NT>), dim3((unsigned)(a.tiles_n * a.nslots)), dim3(DEEP_NTH), smem, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_deep_conv(const DeepArgs& a0, DeepTile t, hipStream_t s) {
+    DeepArgs a = a0;
+    if (a.KS < 1 || (a.KS & (a.KS - 1)) || a.KS > 8 || (a.nrg != 1 && a.nrg != 2)) return hipErrorInvalidValue;
+    if (a.CSm < 16 || (a.CSm & (a.CSm - 1)) || a.CSm > 256 || a.CSm * a.KS != a.Cmain) return hipErrorInvalidValue;
+    if (a.Cskip && (a.CSs * a.KS != a.Cskip || (a.CSs & (a.CSs - 1)) || a.CSs < 16 || a.CSs > 256)) return hipErrorInvalidValue;
+    if (a.gn && ((a.gs & 3) || (a.gs & (a.gs - 1)) || a.CSm % a.gs || a.CSm / a.gs > DEEP_MAX_NG)) return hipErrorInvalidValue;
+    if (a.N % (16 * t.NT) || (a.N & 3)) return hipErrorInvalidValue;
+    if (a.gn && a.whole && a.nrg != 1) return hipErrorInvalidValue;      // statistics over all planes need all planes in one workgroup
+    if (!a.zeros) return hipErrorInvalidValue;
+    if (!a.gn) { a.gamma = a.beta = a.zeros; }                           // (the kernel loads these vectors unconditionally)
+    if (!a.gn || !a.film) { a.film = a.zeros; a.film_stride = 0; }
+    a.tiles_n = a.N / (16 * t.NT);
+    a.ks_shift = __builtin_ctz(a.KS);
+    a.cpt_shift = __builtin_ctz(a.CSm / 16);
+    a.nmain_ch = a.ntaps * (a.CSm / 16);
+    a.nch = a.nmain_ch + (a.Cskip ? a.CSs / 16 : 0);
+    a.nslots = a.B * a.nrg * a.KS;
+    a.inv_nslots = 1.0f / (float)a.nslots;
+    a.inv_r = 1.0f / (float)a.r;
+    a.inv_rs = 0.f;
+    {   // reciprocal element counts of the GroupNorm statistics (source level): planes 0, 1, 2 and all planes together
+        const int rs = a.up_main ? a.r >> 1 : a.r, ts = a.up_main ? a.t >> 1 : a.t;
+        const double gsd = a.gn ? (double)a.gs : 1.0;
+        a.inv_n[0] = 1.0 / ((double)rs * rs * gsd);
+        a.inv_n[1] = a.inv_n[2] = 1.0 / ((double)ts * rs * gsd);
+        a.inv_n[3] = 1.0 / ((double)(rs * rs + 2 * ts * rs) * gsd);
+    }
+    const size_t smem = deep_layout(a, t);
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+#define MTV_DEEP_GO(R, N) if (t.RT == R && t.NT == N) return deep_launch_t<R, N>(a, smem, s)
+    MTV_DEEP_GO(1, 1); MTV_DEEP_GO(2, 1); MTV_DEEP_GO(4, 1); MTV_DEEP_GO(8, 1);
+    MTV_DEEP_GO(1, 3); MTV_DEEP_GO(2, 3); MTV_DEEP_GO(4, 3); MTV_DEEP_GO(8, 3);
+#undef MTV_DEEP_GO
+    return hipErrorInvalidValue;
+}
+
+hipError_t deep_init_attrs() {
+    const void* fn[] = {reinterpret_cast<const void*>(&k_deep_conv<1, 1>), reinterpret_cast<const void*>(&k_deep_conv<2, 1>),
+                        reinterpret_cast<const void*>(&k_deep_conv<4, 1>), reinterpret_cast<const void*>(&k_deep_conv<8, 1>),
+                        reinterpret_cast<const void*>(&k_deep_conv<1, 3>), reinterpret_cast<const void*>(&k_deep_conv<2, 3>),
+                        reinterpret_cast<const void*>(&k_deep_conv<4, 3>), reinterpret_cast<const void*>(&k_deep_conv<8, 3>)};
+    for (const void* f : fn) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_deep_repack(const float* W, int ldw, float* dst, const DeepArgs& a0, int NT, hipStream_t s) {
+    DeepArgs a = a0;
+    a.cpt_shift = __builtin_ctz(a.CSm / 16);
+    a.nmain_ch = a.ntaps * (a.CSm / 16);
+    a.nch = a.nmain_ch + (a.Cskip ? a.CSs / 16 : 0);
+    const long total = (long)deep_weight_floats(a, NT);
+    hipLaunchKernelGGL(k_deep_repack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, ldw, dst, a, NT, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_deep_finalize(const DeepFinArgs& a, hipStream_t s) {
+    if (a.nstat < 0 || a.nstat > 2 || (a.src.C & 3) || a.src.ks < 1 || a.src.ks > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_deep_finalize, dim3((unsigned)((a.src.C + 63) / 64), (unsigned)((a.L + 7) / 8), (unsigned)a.B), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace mtv

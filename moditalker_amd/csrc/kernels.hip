@@ -323,11 +323,18 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
                 const float* qp = qrow + (D == 16 ? 8 * (g & 1) : 32 * ks + 8 * g);
                 qb_raw[ks][0] = *reinterpret_cast<const f32x4*>(qp);
                 qb_raw[ks][1] = *reinterpret_cast<const f32x4*>(qp + 4);
+                for (int sl = 1; sl < a.qkv_ks; ++sl) {           // deep levels (deep.hip): qkv = sum of K-slice slabs, slab order
+                    qb_raw[ks][0] += *reinterpret_cast<const f32x4*>(qp + (size_t)sl * a.qkv_slab);
+                    qb_raw[ks][1] += *reinterpret_cast<const f32x4*>(qp + (size_t)sl * a.qkv_slab + 4);
+                }
             }
         } else {
             const float* qp = qrow + VW * g;
 #pragma unroll
-            for (int u = 0; u < NV; ++u) qraw[u] = *reinterpret_cast<const qvec_t*>(qp + 16 * u);
+            for (int u = 0; u < NV; ++u) {
+                qraw[u] = *reinterpret_cast<const qvec_t*>(qp + 16 * u);
+                for (int sl = 1; sl < a.qkv_ks; ++sl) qraw[u] += *reinterpret_cast<const qvec_t*>(qp + (size_t)sl * a.qkv_slab + 16 * u);
+            }
         }
     }
     f32x4 oacc[NOB];
@@ -349,6 +356,10 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
             // select here puts the wait for the loads right behind their issue, i.e. in front of the block's math
             kreg[r] = *reinterpret_cast<const f32x4*>(p);
             vreg[r] = *reinterpret_cast<const f32x4*>(p + D);
+            for (int sl = 1; sl < a.qkv_ks; ++sl) {               // deep levels: the K-slice slabs of qkv, slab order
+                kreg[r] += *reinterpret_cast<const f32x4*>(p + (size_t)sl * a.qkv_slab);
+                vreg[r] += *reinterpret_cast<const f32x4*>(p + (size_t)sl * a.qkv_slab + D);
+            }
         }
     };
     auto lstore = [&](int buf, int kb) {

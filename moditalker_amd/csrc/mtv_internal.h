@@ -226,6 +226,72 @@ struct AttnArgs {
     int Lkv;
     const unsigned char* kmask;   // [B][Lkv] or nullptr: 0 = key masked out
     unsigned long long* dbg;      // diagnostic build (-DMTV_ATT_STAMP): phase timestamps of four sampled workgroups, else unused
+    // deep levels (deep.hip): `qkv` is the sum of qkv_ks partial slabs, qkv_slab floats apart (0 / 1: a plain tensor)
+    int qkv_ks;
+    unsigned qkv_slab;
+};
+
+// ---- deep levels (<= 128 tokens per clip): K-sliced convs whose partial results are summed by the CONSUMER (deep.hip) ----
+// A tensor of the deep region is a sum of `ks` partial slabs [B][L][C] (`slab_stride` floats apart): the K slices of the conv
+// that produced it, slice 0 carrying bias + residual.  Nobody finishes the split-K sum in the producing launch (no slab
+// round trip, no ticket, no statistics atomics): every consumer adds the slabs of the channel slice it reads, in slab order
+// (run-to-run bit-equal), and computes the GroupNorm statistics of that slice itself -- at <= 128 tokens a workgroup holds
+// all tokens of its channel slice.  ks == 1 is a plain tensor.
+struct DeepSrc {
+    const float* p;          // slab 0 (nullptr: absent)
+    unsigned slab_stride;    // floats between slabs
+    int ks;                  // slabs: 1, 2, 4 or 8
+    int C;                   // channels = row stride
+};
+
+struct DeepArgs {
+    DeepSrc main[2];         // tapped source, <= 2 parts concatenated along channels (main[1].p == nullptr: one part)
+    DeepSrc skip[2];         // parts of the fused 1x1 skip conv (raw, rows = output tokens); skip[0].p == nullptr: none
+    DeepSrc res;             // residual added by K slice 0 (res.p == nullptr: none)
+    int Cmain, Cskip;        // channels of the concatenations
+    int ntaps;               // 9 (3x3 on the tri-plane grid) or 1
+    int up_main, up_res;     // 1: that source lives on the next-coarser level (nearest x2 upsampling folded into the row map)
+    int r, t;                // plane geometry of the OUTPUT level: xy r x r | yt t x r | xt t x r
+    int B, Lout, Lsrc, Lres; // tokens per clip: output, tapped source, residual source
+    int N;                   // output channels (multiple of 16 NT)
+    const float* W;          // deep layout [column tile][K slice][chunk][NT][64 lanes][4]  (k_deep_repack)
+    const float* bias;       // [N]
+    const float* bias2;      // [N] or nullptr (bias of the fused skip conv)
+    const float* bias_b;     // per clip [B][bias_b_stride] or nullptr
+    int bias_b_stride;
+    const float* gamma;      // GroupNorm of the tapped source (gn != 0): [Cmain]
+    const float* beta;
+    const float* film;       // per clip: scale at [c], shift at [Cmain + c]; nullptr = none
+    int film_stride;
+    int gs;                  // channels per group
+    int gn, whole, act;      // gn: normalise; whole: statistics over all planes (AttentionBlock1D); act: SiLU
+    const float* zeros;      // >= 2 Cmain zero floats: stands in for absent GroupNorm / FiLM vectors (launch_deep_conv)
+    float* out;              // slab 0 of the output [KS][B][Lout][N]
+    unsigned out_slab_stride;
+    int KS;                  // K slices = output slabs (power of two)
+    int CSm, CSs;            // channels per K slice of the tapped source / of the skip source (CSm: power of two multiple of 16)
+    int nrg;                 // row groups per clip: 1 = all planes, 2 = {xy}, {yt, xt}
+    int tiles_n;             // column tiles (N / 16 NT)
+    // ---- derived by launch_deep_conv
+    int ks_shift, cpt_shift; // log2(KS), log2(CSm / 16)
+    int nmain_ch, nch;       // 16-channel chunks per slice: ntaps * CSm / 16, + CSs / 16
+    int nslots;              // B * nrg * KS
+    float inv_nslots, inv_r, inv_rs;
+    int lds_skip, lds_idx, lds_stat, lds_red;   // LDS offsets (floats): skip slice | row table | statistics scratch | reduction scratch
+    int src_rows_max;        // rows of the staged main slice (largest row group) -- its zero row follows
+    double inv_n[4];         // 1 / (tokens x gs) of source plane 0, 1, 2 and of all planes together
+    unsigned long long* dbg; // -DMTV_DEEP_STAMP builds (tools/ubench/deep_bench): phase timestamps of two sampled workgroups, else unused
+};
+
+// slabs -> one plain tensor (+ GroupNorm statistics into the site tables of legacy consumers): the exits of the deep region
+struct DeepFinArgs {
+    DeepSrc src;
+    float* out;              // [B][L][C]
+    int B, L;
+    SegInfo seg;
+    StatOut stat[2];
+    int nstat;
+    unsigned stat_cstride;
 };
 
 struct LinearArgs {
@@ -288,6 +354,16 @@ hipError_t attn_b3_init_attrs();
 extern int g_attn_qb_default, g_attn_qb_force;   // k_attention<..., QB>: QK^T on the bf16 matrix pipe (kernels.hip)
 extern int g_attn_b3_mode;          // -1 auto (segments of >= g_attn_b3_min_keys keys), 0 never, 1 every eligible launch (mtv_debug_attention_b3 / MTV_ATT_B3)
 extern int g_attn_b3_min_keys;
+// deep levels (deep.hip)
+struct DeepTile { int RT, NT; };                 // k_deep_conv<RT, NT>: 16 RT rows x 16 NT columns per workgroup
+size_t deep_weight_floats(const DeepArgs& a, int NT);
+bool deep_tile_for(const DeepArgs& a, DeepTile* t);      // (fills nothing in `a`; false: no instantiation for this row-group size)
+bool deep_configure(DeepArgs& a, DeepTile* t);           // picks row groups / K slices / tile; false: this conv stays on k_conv
+size_t deep_smem_bytes(const DeepArgs& a, DeepTile t);
+hipError_t launch_deep_conv(const DeepArgs& a, DeepTile t, hipStream_t s);
+hipError_t launch_deep_repack(const float* W, int ldw, float* dst, const DeepArgs& a, int NT, hipStream_t s);   // legacy [krow][ldw] -> deep layout
+hipError_t launch_deep_finalize(const DeepFinArgs& a, hipStream_t s);
+hipError_t deep_init_attrs();
 hipError_t launch_linear(const LinearArgs& a, hipStream_t s);
 hipError_t launch_time_sinusoid(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
 hipError_t launch_pack_input(const float* x, const float* cond, const float* image_cond, int ic_len,

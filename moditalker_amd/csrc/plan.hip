@@ -198,6 +198,8 @@ static bool table_matches_formula(const std::vector<int>& h, int ntaps, bool upm
 // =====================================================================================
 // plan builder
 // =====================================================================================
+static int g_deep_mode = -1;       // mtv_debug_deep: -1 = MTV_DEEP / default (on), 0 = every conv on k_conv, 1 = on
+
 namespace {
 
 struct Builder {
@@ -211,6 +213,8 @@ struct Builder {
     int film_stride;     // floats between batch elements of film_out (0 in a sampler step)
     std::string err;
     std::map<const float*, std::shared_ptr<ConvOp>> producer;   // tensor -> the conv that writes it
+    std::map<const float*, std::shared_ptr<FinOp>> fin_producer;   // plain copy of a deep tensor -> the finalize pass that writes it
+    std::map<const float*, Tens> fin_cache;                        // deep tensor (slab 0) -> its plain copy, made once
 
     Builder(mtv_ctx* ctx, Plan* p, int batch, int md)
         : c(ctx), plan(p), B(batch), mode(md), f(ctx->cfg), emb(ctx->emb_dim), film_out(nullptr), film_stride(0) {}
@@ -300,6 +304,93 @@ struct Builder {
         push(op->base_name + conv_tag(op->a, op->t), [op](hipStream_t s) { return launch_conv(op->a, op->t, s); }, flops, bytes);
     }
 
+
+    // ---- deep levels (deep.hip): K-sliced convs whose consumers add the partial slabs and compute the GroupNorm statistics ----
+    bool deep_on(int lvl) const {
+        static const bool env = []() { const char* e = getenv("MTV_DEEP"); return !e || atoi(e) != 0; }();
+        const bool on = g_deep_mode < 0 ? env : g_deep_mode != 0;
+        return on && B <= 2 && c->lv[lvl].L <= 128;
+    }
+    static DeepSrc dsrc(const Tens& t) { return DeepSrc{t.p, t.slab, t.ks, t.C}; }
+    static std::string deep_tag(const DeepArgs& a, const DeepTile& t) {
+        char tag[96];
+        snprintf(tag, sizeof tag, "[%dx%d k%d d%d,%d,%d,%d]", a.Lout, a.N, a.ntaps * a.Cmain + a.Cskip, t.RT, t.NT, a.KS, a.nrg);
+        return tag;
+    }
+    // common fields of a deep conv at output level `lvl`
+    DeepArgs deep_args(int lvl, int ntaps, int N, const float* bias) {
+        DeepArgs a{};
+        a.ntaps = ntaps;
+        a.r = c->lv[lvl].r;
+        a.t = c->lv[lvl].t;
+        a.B = B;
+        a.Lout = a.Lsrc = a.Lres = c->lv[lvl].L;
+        a.N = N;
+        a.bias = bias;
+        a.zeros = c->buf("deep.zeros", 8192);
+        return a;
+    }
+    // emit a configured deep conv (deep_configure() succeeded): output slabs, deep-layout weights, the op
+    Tens emit_deep(DeepArgs a, DeepTile t, const float* W, int ldw, const std::string& name, int lvl_out) {
+        Tens out;
+        out.lvl = lvl_out;
+        out.C = a.N;
+        out.ks = a.KS;
+        out.slab = (unsigned)((size_t)c->cfg.max_batch * c->lv[lvl_out].L * a.N);
+        // (8 slabs whatever this plan picked: plans of other batch sizes share the buffer and may slice differently)
+        out.p = c->buf("act.deep." + name, (size_t)8 * out.slab);
+        c->taps[name] = {lvl_out, a.N};
+        c->bufs["tap." + name] = out.p;
+        c->tap_slabs[name] = {out.ks, out.slab};
+        a.out = out.p;
+        a.out_slab_stride = out.slab;
+        a.W = c->wdeep_for(W, ldw, a, t.NT);
+        if (!a.W || !out.p || !a.zeros) { err = "deep conv allocation failed at " + name; return Tens{}; }
+        if (c->accounting) {
+            const double m = (double)a.Lout;
+            c->work.flops_conv3x3 += a.ntaps == 9 ? 2.0 * m * a.N * 9.0 * a.Cmain : 0.0;
+            c->work.flops_1x1 += (a.ntaps == 1 ? 2.0 * m * a.N * a.Cmain : 0.0) + 2.0 * m * a.N * a.Cskip;
+            const double wbytes = 4.0 * ((double)a.ntaps * a.Cmain + a.Cskip) * a.N + 4.0 * a.N;
+            if (a.ntaps == 9) {
+                c->work.bytes_weights_conv += wbytes;
+                c->work.bytes_act_conv_path += 4.0 * ((double)a.Lsrc * a.Cmain + (double)a.Lout * a.N + (double)a.Lout * a.Cskip + (a.res.p ? (double)a.Lout * a.N : 0.0));
+            } else {
+                c->work.bytes_weights_other += wbytes;
+            }
+        }
+        auto op = std::make_shared<DeepOp>();
+        op->a = a;
+        op->t = t;
+        const double K = (double)a.ntaps * a.Cmain + a.Cskip;
+        const double flops = 2.0 * B * a.Lout * a.N * K;
+        const double bytes = 4.0 * (K * a.N + a.N) + 4.0 * B * ((double)a.Lsrc * a.Cmain + (double)a.Lout * a.Cskip + (double)a.Lout * a.N + (a.res.p ? (double)a.Lout * a.N : 0.0));
+        push(std::string(a.ntaps == 9 ? "conv3:" : "conv1:") + name + deep_tag(a, t), [op](hipStream_t s) { return launch_deep_conv(op->a, op->t, s); }, flops, bytes);
+        return out;
+    }
+    // a plain copy of a deep tensor for a consumer outside the deep region (k_conv, k_pool_down): made once per tensor
+    Tens materialize(const Tens& x, const std::string& name) {
+        if (x.ks <= 1) return x;
+        auto it = fin_cache.find(x.p);
+        if (it != fin_cache.end()) return it->second;
+        Tens o;
+        o.lvl = x.lvl;
+        o.C = x.C;
+        o.p = c->act(name + ".fin", x.lvl, x.C);
+        auto op = std::make_shared<FinOp>();
+        op->a.src = dsrc(x);
+        op->a.out = o.p;
+        op->a.B = B;
+        op->a.L = c->lv[x.lvl].L;
+        op->a.seg = c->lv[x.lvl].seg();
+        op->a.stat_cstride = (unsigned)c->stats_copy_doubles;
+        fin_producer[o.p] = op;
+        fin_cache[x.p] = o;
+        char tag[64];
+        snprintf(tag, sizeof tag, "[%dx%d ks%d]", op->a.L, x.C, x.ks);
+        push("fin:" + name + tag, [op](hipStream_t s) { return launch_deep_finalize(op->a, s); }, 0.0, 4.0 * B * (double)op->a.L * x.C * (x.ks + 1));
+        return o;
+    }
+
     // GroupNorm site over the channel concatenation of `parts`: the statistics are accumulated by the
     // epilogues of the convs that produce the parts; a standalone pass is only the fallback.
     void add_stats(const std::vector<Tens>& parts, int lvl, double* site) {
@@ -308,13 +399,21 @@ struct Builder {
         bool fused = true;
         for (auto& p : parts) {
             auto it = producer.find(p.p);
-            if (it == producer.end() || it->second->a.nstat >= 2 || it->second->a.out_cm) fused = false;
+            auto fi = fin_producer.find(p.p);
+            if (fi != fin_producer.end()) { if (fi->second->a.nstat >= 2) fused = false; }
+            else if (it == producer.end() || it->second->a.nstat >= 2 || it->second->a.out_cm) fused = false;
         }
         if (fused) {
             int coff = 0;
             for (auto& p : parts) {
-                ConvArgs& pa = producer[p.p]->a;
-                pa.stat[pa.nstat++] = StatOut{site, ct / 32, coff, 1.0f / (float)(ct / 32)};
+                auto fi = fin_producer.find(p.p);
+                if (fi != fin_producer.end()) {
+                    DeepFinArgs& fa = fi->second->a;
+                    fa.stat[fa.nstat++] = StatOut{site, ct / 32, coff, 1.0f / (float)(ct / 32)};
+                } else {
+                    ConvArgs& pa = producer[p.p]->a;
+                    pa.stat[pa.nstat++] = StatOut{site, ct / 32, coff, 1.0f / (float)(ct / 32)};
+                }
                 coff += p.C;
             }
             return;
@@ -377,6 +476,76 @@ struct Builder {
             sb = c->wcopy(P + "skip_connection.bias", {r.cout});
         }
 
+        if (deep_on(lvl_out) && !(r.updown == 1 && x.size() != 1) && !(has_skip_conv && r.updown) && (has_skip_conv || x.size() == 1)) {
+            // ---- deep level: both convs K-sliced, partial slabs summed by their consumers (deep.hip)
+            const bool down = r.updown == 1, up = r.updown == 2;
+            DeepArgs a1 = deep_args(lvl_out, 9, r.cout, cb1);
+            a1.Cmain = cin;
+            if (down) {
+                a1.main[0] = DeepSrc{a1.zeros, 0, 1, cin};                 // (placeholder for the pooled, already normalised input)
+            } else {
+                for (size_t i = 0; i < x.size(); ++i) a1.main[i] = dsrc(x[i]);
+                a1.up_main = up ? 1 : 0;
+                a1.Lsrc = Li.L;
+                a1.gn = 1; a1.act = 1; a1.gs = cin / 32; a1.gamma = g1; a1.beta = b1;
+            }
+            if (!f.use_scale_shift_norm) { a1.bias_b = film_out + r.film_off; a1.bias_b_stride = film_stride; }
+            DeepArgs a2 = deep_args(lvl_out, 9, r.cout, cb2);
+            a2.Cmain = r.cout;
+            a2.main[0] = DeepSrc{a2.zeros, 0, 8, r.cout};                  // (placeholder for h1)
+            a2.gn = 1; a2.act = 1; a2.gs = r.cout / 32; a2.gamma = g2; a2.beta = b2;
+            if (f.use_scale_shift_norm) { a2.film = film_out + r.film_off; a2.film_stride = film_stride; }
+            if (has_skip_conv) {
+                for (size_t i = 0; i < x.size(); ++i) a2.skip[i] = dsrc(x[i]);
+                a2.Cskip = cin;
+                a2.bias2 = sb;
+            } else if (down) {
+                a2.res = DeepSrc{a2.zeros, 0, 1, r.cout};                  // (placeholder for the pooled x)
+            } else {
+                a2.res = dsrc(x[0]);
+                a2.up_res = up ? 1 : 0;
+                a2.Lres = Li.L;
+            }
+            DeepTile t1{}, t2{};
+            if (deep_configure(a1, &t1) && deep_configure(a2, &t2)) {
+                if (down) {
+                    const Tens x0 = materialize(x[0], nm + ".x");         // k_pool_down reads a plain tensor + its statistics
+                    double* site1 = c->new_site();
+                    add_stats({x0}, lvl_in, site1);
+                    Tens pa, px;
+                    pa.lvl = lvl_out; pa.C = cin; pa.p = c->act(nm + ".pool_act", lvl_out, cin);
+                    px.lvl = lvl_out; px.C = cin; px.p = c->act(nm + ".pool_x", lvl_out, cin);
+                    PoolArgs pl{};
+                    pl.x = x0.p; pl.out_act = pa.p; pl.out_x = px.p; pl.sums = site1; pl.cstride = (unsigned)c->stats_copy_doubles; pl.gamma = g1; pl.beta = b1;
+                    pl.B = B; pl.C = cin; pl.gs = cin / 32; pl.seg_src = Li.seg(); pl.seg_dst = Lo.seg(); pl.r_dst = Lo.r; pl.t_dst = Lo.t;
+                    push("pool_down", [pl](hipStream_t s) { return launch_pool_down(pl, s); });
+                    a1.main[0] = dsrc(pa);
+                    a2.res = dsrc(px);
+                }
+                const Tens h1d = emit_deep(a1, t1, W1, ld1, nm + ".h1", lvl_out);
+                if (!err.empty()) return Tens{};
+                a2.main[0] = dsrc(h1d);
+                return emit_deep(a2, t2, W2, ld2, nm + ".out", lvl_out);
+            }
+        }
+        {   // k_conv / k_pool_down read plain tensors: inputs that come out of the deep region are summed up first
+            std::vector<Tens> xl;
+            for (size_t i = 0; i < x.size(); ++i) xl.push_back(materialize(x[i], nm + ".in" + std::to_string(i)));
+            return resblock_legacy(xl, ly, nm, W1, ld1, W2, ld2, g1, b1, cb1, g2, b2, cb2, sb);
+        }
+    }
+
+    Tens resblock_legacy(const std::vector<Tens>& x, const Layer& ly, const std::string& nm, float* W1, int ld1, float* W2, int ld2, float* g1, float* b1,
+                         float* cb1, float* g2, float* b2, float* cb2, float* sb) {
+        const ResDesc& r = ly.res;
+        const int lvl_in = x[0].lvl;
+        const int lvl_out = r.updown == 1 ? lvl_in + 1 : (r.updown == 2 ? lvl_in - 1 : lvl_in);
+        const Level& Lo = c->lv[lvl_out];
+        const Level& Li = c->lv[lvl_in];
+        const std::string P = ly.pre;
+        int cin = 0;
+        for (auto& t : x) cin += t.C;
+        const bool has_skip_conv = cin != r.cout;
         // GN1 statistics of x (per plane)
         double* site1 = c->new_site();
         add_stats(x, lvl_in, site1);
@@ -464,8 +633,40 @@ struct Builder {
     }
 
     // ---- AttentionBlock / AttentionBlock1D (unet.py:210-300) ----
-    Tens attention(const Tens& x, const std::string& P, bool whole, const std::string& nm) {
-        const int C = x.C, lvl = x.lvl;
+    AttnArgs attn_args(const float* qkv, float* att, const Level& L, int C, int H, int d, bool whole) {
+        AttnArgs t{};
+        t.qkv = qkv; t.out = att; t.B = B; t.L = L.L; t.C = C; t.H = H;
+        t.scale = 1.0f / std::sqrt(std::sqrt((float)d));
+        if (whole) {
+            t.nseg = 1; t.seg_start[0] = 0; t.seg_len[0] = L.L;
+        } else {
+            t.nseg = 3;
+            t.seg_start[0] = 0; t.seg_len[0] = L.b1;
+            t.seg_start[1] = L.b1; t.seg_len[1] = L.b2 - L.b1;
+            t.seg_start[2] = L.b2; t.seg_len[2] = L.L - L.b2;
+        }
+        t.blk_prefix[0] = 0;
+        for (int i = 0; i < t.nseg; ++i) t.blk_prefix[i + 1] = t.blk_prefix[i] + (t.seg_len[i] + 63) / 64;
+        return t;
+    }
+    void push_attention(AttnArgs t, const std::string& nm, const Level& L, int C, int d, bool whole) {
+        const int H = t.H;
+        if (c->accounting)
+            for (int i = 0; i < t.nseg; ++i) c->work.flops_attn_core += 4.0 * H * (double)t.seg_len[i] * t.seg_len[i] * d;
+        double aflops = 0.0;
+        for (int i = 0; i < t.nseg; ++i) aflops += 4.0 * B * H * (double)t.seg_len[i] * t.seg_len[i] * d;
+        char tag[64];
+        snprintf(tag, sizeof tag, "[L%d d%d %s]", L.L, d, whole ? "1d" : "2d");      // (which core runs is decided at launch: launch_attention)
+        static const bool att_stamps = getenv("MTV_STAMPS") != nullptr;       // diagnostic build only (mtv_debug_stamps)
+        if (att_stamps) {
+            t.dbg = reinterpret_cast<unsigned long long*>(c->buf("dbg.attn." + nm + "." + std::to_string(mode) + "." + std::to_string(B), 128));
+            plan->attn_dbg.emplace_back("attn:" + nm + tag, t.dbg);
+        }
+        push("attn:" + nm + tag, [t](hipStream_t s) { return launch_attention(t, s); }, aflops, 4.0 * B * L.L * 4.0 * C);
+    }
+
+    Tens attention(const Tens& x0, const std::string& P, bool whole, const std::string& nm) {
+        const int C = x0.C, lvl = x0.lvl;
         const Level& L = c->lv[lvl];
         const int H = f.num_heads;
         if (C % H || (C / H) % 4 || C % 32) { err = "attention channels/heads unsupported at " + P; return Tens{}; }
@@ -486,6 +687,30 @@ struct Builder {
         c->slots[c->slot_index[P + "proj_out.weight"]].dst2 = Wp_nk;
         float* bp = c->wcopy(P + "proj_out.bias", {C});
 
+        if (deep_on(lvl)) {
+            DeepArgs dq = deep_args(lvl, 1, 3 * C, bq);
+            dq.Cmain = C;
+            dq.main[0] = dsrc(x0);
+            dq.gn = 1; dq.whole = whole ? 1 : 0; dq.act = 0; dq.gs = C / 32; dq.gamma = gw; dq.beta = gb;
+            DeepArgs dp = deep_args(lvl, 1, C, bp);
+            dp.Cmain = C;
+            dp.main[0] = DeepSrc{dp.zeros, 0, 1, C};                       // (placeholder for the attention output)
+            dp.res = dsrc(x0);
+            DeepTile tq{}, tp{};
+            if (deep_configure(dq, &tq) && deep_configure(dp, &tp)) {
+                const Tens qkvd = emit_deep(dq, tq, Wq, ldq, nm + ".qkv", lvl);
+                if (!err.empty()) return Tens{};
+                float* attd = c->act(nm + ".att", lvl, C);
+                const Tens qkvp = materialize(qkvd, nm + ".qkv");         // (k_attention adds slabs through a serial loop: plain input instead)
+                AttnArgs t = attn_args(qkvp.p, attd, L, C, H, d, whole);
+                push_attention(t, nm, L, C, d, whole);
+                Tens ad;
+                ad.lvl = lvl; ad.C = C; ad.p = attd;
+                dp.main[0] = dsrc(ad);
+                return emit_deep(dp, tp, Wp, ldp, nm + ".out", lvl);
+            }
+        }
+        const Tens x = materialize(x0, nm + ".in");       // k_conv reads a plain tensor and the statistics its producer left
         double* site = c->new_site();
         add_stats({x}, lvl, site);
         float* qkv = c->act(nm + ".qkv", lvl, 3 * C);
@@ -496,31 +721,7 @@ struct Builder {
         add_conv(a, nm + ".qkv", lvl);
 
         float* att = c->act(nm + ".att", lvl, C);
-        AttnArgs t{};
-        t.qkv = qkv; t.out = att; t.B = B; t.L = L.L; t.C = C; t.H = H;
-        t.scale = 1.0f / std::sqrt(std::sqrt((float)d));
-        if (whole) {
-            t.nseg = 1; t.seg_start[0] = 0; t.seg_len[0] = L.L;
-        } else {
-            t.nseg = 3;
-            t.seg_start[0] = 0; t.seg_len[0] = L.b1;
-            t.seg_start[1] = L.b1; t.seg_len[1] = L.b2 - L.b1;
-            t.seg_start[2] = L.b2; t.seg_len[2] = L.L - L.b2;
-        }
-        t.blk_prefix[0] = 0;
-        for (int i = 0; i < t.nseg; ++i) t.blk_prefix[i + 1] = t.blk_prefix[i] + (t.seg_len[i] + 63) / 64;
-        if (c->accounting)
-            for (int i = 0; i < t.nseg; ++i) c->work.flops_attn_core += 4.0 * H * (double)t.seg_len[i] * t.seg_len[i] * d;
-        double aflops = 0.0;
-        for (int i = 0; i < t.nseg; ++i) aflops += 4.0 * B * H * (double)t.seg_len[i] * t.seg_len[i] * d;
-        char tag[64];
-        snprintf(tag, sizeof tag, "[L%d d%d %s]", L.L, d, whole ? "1d" : "2d");      // (which core runs is decided at launch: launch_attention)
-        static const bool att_stamps = getenv("MTV_STAMPS") != nullptr;       // diagnostic build only (mtv_debug_stamps)
-        if (att_stamps) {
-            t.dbg = reinterpret_cast<unsigned long long*>(c->buf("dbg.attn." + nm + "." + std::to_string(mode) + "." + std::to_string(B), 128));
-            plan->attn_dbg.emplace_back("attn:" + nm + tag, t.dbg);
-        }
-        push("attn:" + nm + tag, [t](hipStream_t s) { return launch_attention(t, s); }, aflops, 4.0 * B * L.L * 4.0 * C);
+        push_attention(attn_args(qkv, att, L, C, H, d, whole), nm, L, C, d, whole);
 
         Tens out;
         out.lvl = lvl; out.C = C; out.p = c->act(nm + ".out", lvl, C);
@@ -560,6 +761,8 @@ struct Builder {
         if (st.attn1_c) cur = attention(cur, st.attn1_pre, true, nm + ".a1");
         c->taps[st.tap] = {cur.lvl, cur.C};
         c->bufs["tap." + st.tap] = cur.p;
+        if (cur.ks > 1) c->tap_slabs[st.tap] = {cur.ks, cur.slab};
+        else c->tap_slabs.erase(st.tap);
         return cur;
     }
 
@@ -1023,6 +1226,7 @@ int ctx_init_common(mtv_ctx* c) {
     if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     HIPCHK(conv_init_attrs());     // dynamic LDS above 64 KB must be opted into once per kernel (never under capture)
     HIPCHK(attn_init_attrs());
+    HIPCHK(deep_init_attrs());
     return MTV_OK;
 }
 
@@ -1200,6 +1404,7 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
     }
     s.loaded = true;
     for (auto& kv : c->w3) kv.second.dirty = true;      // (rebuilt before the next run: check_ready)
+    for (auto& kv : c->wdeep) kv.second.dirty = true;
     return MTV_OK;
 }
 
@@ -1219,6 +1424,12 @@ int check_ready(mtv_ctx* c, int batch) {
     for (auto& kv : c->w3)
         if (kv.second.dirty) {
             HIPCHK(launch_split_w3(kv.first, kv.second.p, kv.second.plane_bytes, 0, kv.second.K, kv.second.ld, nullptr));
+            kv.second.dirty = false;
+            any = true;
+        }
+    for (auto& kv : c->wdeep)
+        if (kv.second.dirty) {
+            HIPCHK(launch_deep_repack(kv.second.W, kv.second.ldw, kv.second.p, kv.second.lay, kv.second.NT, nullptr));
             kv.second.dirty = false;
             any = true;
         }
@@ -1495,7 +1706,21 @@ int mtv_debug_tap(mtv_ctx* c, const char* name, float* dst, int64_t cap, int* to
         if (B < 1) return fail(MTV_ERR_INVALID, "tap destination too small");
         if (B > c->cfg.max_batch) B = c->cfg.max_batch;
         HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipMemcpy(dst, c->bufs["tap." + std::string(name)], (size_t)B * L * C * 4, hipMemcpyDefault));
+        const float* src = c->bufs["tap." + std::string(name)];
+        auto sl = c->tap_slabs.find(name);
+        if (sl == c->tap_slabs.end() || sl->second.first <= 1) {
+            HIPCHK(hipMemcpy(dst, src, (size_t)B * L * C * 4, hipMemcpyDefault));
+        } else {
+            // a tensor of the deep levels is the sum of its K-slice slabs (deep.hip): added up here in slab order, as its consumers do
+            const size_t n = (size_t)B * L * C;
+            std::vector<float> acc(n), one(n);
+            HIPCHK(hipMemcpy(acc.data(), src, n * 4, hipMemcpyDeviceToHost));
+            for (int k = 1; k < sl->second.first; ++k) {
+                HIPCHK(hipMemcpy(one.data(), src + (size_t)k * sl->second.second, n * 4, hipMemcpyDeviceToHost));
+                for (size_t e = 0; e < n; ++e) acc[e] += one[e];
+            }
+            HIPCHK(hipMemcpy(dst, acc.data(), n * 4, hipMemcpyDefault));
+        }
     }
     return MTV_OK;
 }
@@ -1524,6 +1749,12 @@ int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up)
     if (res <= 0 || frames <= 0 || tok < 0 || tok >= res * res + 2 * frames * res || ky < 0 || ky > 2 || kx < 0 || kx > 2)
         return fail(MTV_ERR_INVALID, "debug_gather_index: bad arguments") - 1;   // (-2: distinct from "padding")
     return geo_source(res, frames, tok, ky, kx, up != 0);
+}
+
+int mtv_debug_deep(int mode) {
+    if (mode < -1 || mode > 1) return fail(MTV_ERR_INVALID, "mode must be -1 (default), 0 (off) or 1 (on)");
+    g_deep_mode = mode;
+    return MTV_OK;
 }
 
 int mtv_debug_attention_b3(int mode) {

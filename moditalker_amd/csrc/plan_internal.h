@@ -56,6 +56,8 @@ struct Tens {
     float* p = nullptr;
     int C = 0;
     int lvl = 0;
+    int ks = 1;                // deep levels (deep.hip): the tensor is the sum of `ks` partial slabs, `slab` floats apart
+    unsigned slab = 0;
 };
 
 struct ResDesc {
@@ -87,6 +89,14 @@ struct ConvOp {                 // one convolution of the plan; args/tile are pa
     ConvTile t;
     std::string base_name;
     int op_index = -1;
+};
+
+struct DeepOp {                 // one K-sliced conv of the deep levels (deep.hip)
+    DeepArgs a;
+    DeepTile t;
+};
+struct FinOp {                  // slabs -> plain tensor (+ statistics for legacy consumers)
+    DeepFinArgs a;
 };
 
 // A plan is built per (batch size, mode).  FORWARD: one UNetModel.forward for arbitrary per-clip timesteps
@@ -160,6 +170,23 @@ struct mtv_ctx {
     // split-bf16 copies of conv / GEMM weight matrices (k_conv_x3): W [K][ld] f32 -> three bf16 planes, rebuilt after weight loads
     struct W3Info { void* p; size_t plane_bytes; int K, ld; bool dirty; };
     std::map<const float*, W3Info> w3;
+    // deep-layout copies of conv matrices (k_deep_conv): one per (matrix, slicing), rebuilt after weight loads
+    struct WDeepInfo { float* p; const float* W; int ldw; DeepArgs lay; int NT; bool dirty; };
+    std::map<std::string, WDeepInfo> wdeep;
+    std::map<std::string, std::pair<int, unsigned>> tap_slabs;   // tap name -> (slabs, floats between them) of a deep tensor
+    const float* wdeep_for(const float* W, int ldw, const DeepArgs& lay, int NT) {
+        char key[160];
+        snprintf(key, sizeof key, "%p %d %d %d %d %d %d %d %d %d", (const void*)W, ldw, lay.KS, lay.CSm, lay.CSs, NT, lay.ntaps, lay.Cmain, lay.Cskip, lay.N);
+        auto it = wdeep.find(key);
+        if (it == wdeep.end()) {
+            void* p = nullptr;
+            if (dmalloc(&p, deep_weight_floats(lay, NT) * sizeof(float)) != MTV_OK) return nullptr;
+            it = wdeep.emplace(key, WDeepInfo{(float*)p, W, ldw, lay, NT, true}).first;
+            // a plan built lazily (first run at a new batch size) comes after check_ready's refresh: repack what the weight holds now
+            if (launch_deep_repack(W, ldw, (float*)p, lay, NT, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;
+        }
+        return it->second.p;
+    }
     const void* w3_for(const float* W, int K, int ld, unsigned long long* plane_out) {
         if (K & 7) return nullptr;
         auto it = w3.find(W);

@@ -1,0 +1,348 @@
+// k_deep_conv (moditalker_amd/csrc/deep.hip): correctness against a plain CPU conv on the tri-plane grid, and the chain
+// experiment VERDICT r3 item 1 asks for -- a dependent chain of [32 x 512, K = 4608] convs with DISTINCT 9.4 MB weights and a
+// GroupNorm between consecutive ops, (a) as today's k_conv launches (statistics by epilogue atomics, in-launch split-K),
+// (b) as k_deep_conv launches (consumer-side slab sums + statistics), both replayed as one hipGraph.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics deep_bench.hip -o deep_bench
+//   deep_bench check          correctness cases
+//   deep_bench chain [nops] [r t]   timing (default 40 ops = 377 MB of weights: larger than the 256 MB Infinity Cache; r t = 4 2)
+#include "../../moditalker_amd/csrc/conv.hip"
+#include "../../moditalker_amd/csrc/deep.hip"
+#include <cmath>
+#include <functional>
+#include <cstring>
+#include <vector>
+using namespace mtv;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+static unsigned g_seed = 12345;
+static float frand() { g_seed = g_seed * 1664525u + 1013904223u; return ((g_seed >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+template <class T> static T* dnew(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T) + 16)); CK(hipMemset(p, 0, n * sizeof(T) + 16)); return p; }
+static float* dup(const std::vector<float>& h) { float* p = dnew<float>(h.size()); CK(hipMemcpy(p, h.data(), h.size() * 4, hipMemcpyHostToDevice)); return p; }
+
+struct Case {
+    const char* name;
+    int r, t, up;            // output-level geometry; up: tapped source on the coarser level
+    int ntaps, Cm0, Cm1, Cs0, Cs1, N;
+    int gn, whole, act, film, res, up_res;
+    int ks_in, ks_res, KS, nrg, B;
+};
+
+// a slab tensor with a known sum: returns the summed host copy, uploads ks random slabs that add up to it
+static DeepSrc make_src(int B, int L, int C, int ks, std::vector<float>& sum) {
+    sum.assign((size_t)B * L * C, 0.f);
+    std::vector<float> slabs((size_t)ks * B * L * C);
+    for (int k = 0; k < ks; ++k)
+        for (size_t e = 0; e < sum.size(); ++e) slabs[(size_t)k * sum.size() + e] = frand() * (k ? 0.5f : 1.0f);
+    for (size_t e = 0; e < sum.size(); ++e) {          // slab order, as the kernel adds them
+        float s = slabs[e];
+        for (int k = 1; k < ks; ++k) s += slabs[(size_t)k * sum.size() + e];
+        sum[e] = s;
+    }
+    DeepSrc d{};
+    d.p = dup(slabs);
+    d.slab_stride = (unsigned)sum.size();
+    d.ks = ks;
+    d.C = C;
+    return d;
+}
+
+static int run_case(const Case& c) {
+    const int r = c.r, t = c.t, b1 = r * r, b2 = b1 + t * r, L = b2 + t * r;
+    const int rs = c.up ? r / 2 : r, ts = c.up ? t / 2 : t, b1s = rs * rs, b2s = b1s + ts * rs, Ls = b2s + ts * rs;
+    const int rr = c.up_res ? r / 2 : r, tr = c.up_res ? t / 2 : t, Lr = rr * rr + 2 * tr * rr;
+    const int Cmain = c.Cm0 + c.Cm1, Cskip = c.Cs0 + c.Cs1, K = c.ntaps * Cmain + Cskip, ldw = (c.N + 63) / 64 * 64;
+    DeepArgs a{};
+    std::vector<float> xm[2], xs[2], xr;
+    a.main[0] = make_src(c.B, Ls, c.Cm0, c.ks_in, xm[0]);
+    if (c.Cm1) a.main[1] = make_src(c.B, Ls, c.Cm1, c.ks_in > 1 ? c.ks_in / 2 : 1, xm[1]);
+    if (c.Cs0) a.skip[0] = make_src(c.B, L, c.Cs0, c.ks_in, xs[0]);
+    if (c.Cs1) a.skip[1] = make_src(c.B, L, c.Cs1, 1, xs[1]);
+    if (c.res) a.res = make_src(c.B, Lr, c.N, c.ks_res, xr);
+    a.Cmain = Cmain; a.Cskip = Cskip; a.ntaps = c.ntaps; a.up_main = c.up; a.up_res = c.up_res; a.r = r; a.t = t;
+    a.B = c.B; a.Lout = L; a.Lsrc = Ls; a.Lres = Lr; a.N = c.N;
+    std::vector<float> W((size_t)K * ldw), bias(c.N), bias2(c.N), gamma(Cmain), beta(Cmain), film((size_t)c.B * 2 * Cmain);
+    const float wsc = 1.0f / sqrtf((float)K);
+    for (auto& v : W) v = frand() * wsc;
+    for (auto& v : bias) v = frand() * 0.1f;
+    for (auto& v : bias2) v = frand() * 0.1f;
+    for (auto& v : gamma) v = 1.0f + 0.3f * frand();
+    for (auto& v : beta) v = 0.2f * frand();
+    for (auto& v : film) v = 0.3f * frand();
+    float* dW = dup(W);
+    a.bias = dup(bias);
+    if (Cskip) a.bias2 = dup(bias2);
+    a.gn = c.gn; a.whole = c.whole; a.act = c.act; a.gs = Cmain / 32;
+    if (c.gn) { a.gamma = dup(gamma); a.beta = dup(beta); }
+    if (c.film) { a.film = dup(film); a.film_stride = 2 * Cmain; }
+    a.KS = c.KS; a.CSm = Cmain / c.KS; a.CSs = Cskip / c.KS; a.nrg = c.nrg;
+    a.zeros = dnew<float>(2 * Cmain);
+    float* out = dnew<float>((size_t)c.KS * c.B * L * c.N);
+    a.out = out; a.out_slab_stride = (unsigned)((size_t)c.B * L * c.N);
+    DeepTile tl{};
+    if (!deep_tile_for(a, &tl)) { printf("%-28s no tile\n", c.name); return 1; }
+    float* dWd = dnew<float>(deep_weight_floats(a, tl.NT));
+    a.tiles_n = c.N / (16 * tl.NT);
+    CK(launch_deep_repack(dW, ldw, dWd, a, tl.NT, 0));
+    a.W = dWd;
+    CK(hipMemset(out, 0xFF, (size_t)c.KS * c.B * L * c.N * 4));        // poison: NaN wherever nothing is written
+    CK(launch_deep_conv(a, tl, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<float> got((size_t)c.KS * c.B * L * c.N);
+    CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+    // ---- CPU reference (double accumulation)
+    std::vector<double> ref((size_t)c.B * L * c.N, 0.0);
+    auto xmain = [&](int b, int tok, int ch) -> float { return ch < c.Cm0 ? xm[0][((size_t)b * Ls + tok) * c.Cm0 + ch] : xm[1][((size_t)b * Ls + tok) * c.Cm1 + ch - c.Cm0]; };
+    std::vector<float> act((size_t)c.B * Ls * Cmain);
+    for (int b = 0; b < c.B; ++b) {
+        const int gs = Cmain / 32;
+        for (int g = 0; g < 32; ++g)
+            for (int p = 0; p < (c.whole ? 1 : 3); ++p) {
+                const int t0 = c.whole ? 0 : (p == 0 ? 0 : (p == 1 ? b1s : b2s)), t1 = c.whole ? Ls : (p == 0 ? b1s : (p == 1 ? b2s : Ls));
+                double s = 0, ss = 0;
+                for (int tok = t0; tok < t1; ++tok)
+                    for (int ch = g * gs; ch < (g + 1) * gs; ++ch) { const double v = xmain(b, tok, ch); s += v; ss += v * v; }
+                const double n = (double)(t1 - t0) * gs, mean = s / n, var = std::max(0.0, ss / n - mean * mean), rstd = 1.0 / sqrt(var + 1e-5);
+                for (int tok = t0; tok < t1; ++tok)
+                    for (int ch = g * gs; ch < (g + 1) * gs; ++ch) {
+                        double v = xmain(b, tok, ch);
+                        if (c.gn) {
+                            v = (v - mean) * rstd * gamma[ch] + beta[ch];
+                            if (c.film) v = v * (1.0 + film[(size_t)b * 2 * Cmain + ch]) + film[(size_t)b * 2 * Cmain + Cmain + ch];
+                            if (c.act) v = v / (1.0 + exp(-v));
+                        }
+                        act[((size_t)b * Ls + tok) * Cmain + ch] = (float)v;
+                    }
+            }
+    }
+    for (int b = 0; b < c.B; ++b)
+        for (int tok = 0; tok < L; ++tok) {
+            double* o = &ref[((size_t)b * L + tok) * c.N];
+            for (int tap = 0; tap < c.ntaps; ++tap) {
+                int src;
+                if (c.ntaps == 9) {
+                    const int g = geo_source(r, t, tok, tap / 3, tap % 3, c.up != 0);
+                    if (g < 0) continue;
+                    src = g & 0x0FFFFFFF;
+                } else src = c.up ? (geo_source(r, t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
+                const float* ar = &act[((size_t)b * Ls + src) * Cmain];
+                for (int ch = 0; ch < Cmain; ++ch) {
+                    const double av = ar[ch];
+                    const float* wr = &W[((size_t)tap * Cmain + ch) * ldw];
+                    for (int n = 0; n < c.N; ++n) o[n] += av * wr[n];
+                }
+            }
+            for (int ch = 0; ch < Cskip; ++ch) {
+                const double av = ch < c.Cs0 ? xs[0][((size_t)b * L + tok) * c.Cs0 + ch] : xs[1][((size_t)b * L + tok) * c.Cs1 + ch - c.Cs0];
+                const float* wr = &W[((size_t)c.ntaps * Cmain + ch) * ldw];
+                for (int n = 0; n < c.N; ++n) o[n] += av * wr[n];
+            }
+            const int rtok = c.up_res ? (geo_source(r, t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
+            for (int n = 0; n < c.N; ++n) {
+                o[n] += bias[n] + (Cskip ? bias2[n] : 0.f);
+                if (c.res) o[n] += xr[((size_t)b * Lr + rtok) * c.N + n];
+            }
+        }
+    double worst = 0.0, scale = 0.0;
+    bool nan = false;
+    for (size_t e = 0; e < ref.size(); ++e) {
+        double s = 0;
+        for (int k = 0; k < c.KS; ++k) { const float v = got[(size_t)k * ref.size() + e]; if (v != v) nan = true; s += v; }
+        worst = std::max(worst, fabs(s - ref[e]));
+        scale = std::max(scale, fabs(ref[e]));
+    }
+    const bool ok = !nan && worst <= 2e-5 * std::max(1.0, scale) * 4;
+    printf("%-28s tile RT%d NT%d KS%d nrg%d  max|err| %.3e (|ref| <= %.2f)%s  %s\n", c.name, tl.RT, tl.NT, c.KS, c.nrg, worst, scale, nan ? " NaN" : "", ok ? "PASS" : "FAIL");
+    return ok ? 0 : 1;
+}
+
+static int do_check() {
+    const Case cases[] = {
+        // name                       r  t up taps Cm0  Cm1  Cs0  Cs1   N  gn wh act film res upr ksi ksr KS nrg B
+        {"m32 conv3 gn",              4, 2, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 0, 0, 0, 1, 1, 8, 1, 1},
+        {"m32 conv3 gn film res ks",  4, 2, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 1, 1, 0, 8, 4, 8, 1, 1},
+        {"m32 conv3 cat+skipconv",    4, 2, 0, 9, 128,   0, 128, 128, 128, 1, 0, 1, 1, 0, 0, 4, 1, 4, 1, 1},
+        {"m32 conv3 cat main",        4, 2, 0, 9, 128, 128,   0,   0, 128, 1, 0, 1, 0, 0, 0, 4, 1, 8, 1, 1},
+        {"m32 1x1 whole qkv",         4, 2, 0, 1, 128,   0,   0,   0, 384, 1, 1, 0, 0, 0, 0, 8, 1, 8, 1, 1},
+        {"m32 1x1 raw + res",         4, 2, 0, 1, 128,   0,   0,   0, 128, 0, 0, 0, 0, 1, 0, 1, 8, 2, 1, 1},
+        {"m128 conv3 rg2",            8, 4, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 1, 1, 0, 4, 4, 4, 2, 1},
+        {"m128 conv3 rg1",            8, 4, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 0, 0, 0, 2, 1, 8, 1, 1},
+        {"m128 conv3 up rg2",         8, 4, 1, 9, 128,   0,   0,   0, 128, 1, 0, 1, 0, 0, 0, 8, 1, 4, 2, 1},
+        {"m128 conv3 up_res rg2",     8, 4, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 1, 1, 1, 4, 8, 4, 2, 1},
+        {"m128 1x1 whole rg1 NT3",    8, 4, 0, 1, 256,   0,   0,   0, 768, 1, 1, 0, 0, 0, 0, 4, 1, 8, 1, 1},
+        {"m128 1x1 2d rg2",           8, 4, 0, 1, 128,   0,   0,   0, 384, 1, 0, 0, 0, 0, 0, 4, 1, 4, 2, 1},
+        {"m128 B2 conv3 rg2",         8, 4, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 1, 1, 0, 4, 2, 4, 2, 2},
+        {"ragged r6 t3 conv3",        6, 3, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 0, 1, 0, 2, 2, 4, 2, 1},
+        {"ragged r3 t1 conv3 rg1",    3, 1, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 0, 0, 0, 2, 1, 8, 1, 1},
+        {"full m32 k4608",            4, 2, 0, 9, 512,   0,   0,   0, 512, 1, 0, 1, 1, 1, 0, 8, 8, 8, 1, 1},
+        {"full m32 out conv2 k5632",  4, 2, 0, 9, 512,   0, 512, 512, 512, 1, 0, 1, 1, 0, 0, 8, 1, 8, 1, 1},
+        {"full m128 k9216 rg2",       8, 4, 0, 9, 512, 512,   0,   0, 512, 1, 0, 1, 0, 0, 0, 4, 1, 4, 2, 1},
+        {"full m128 qkv whole",       8, 4, 0, 1, 512,   0,   0,   0, 1536, 1, 1, 0, 0, 0, 0, 4, 1, 8, 1, 1},
+    };
+    int bad = 0;
+    for (auto& c : cases) bad += run_case(c);
+    printf("%s (%d failing)\n", bad ? "CHECK FAILED" : "CHECK OK", bad);
+    return bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- chain timing
+static void do_chain(int nops, int r, int t, int ks_arg, int nrg_arg) {
+    const int C = 512, N = 512, K = 9 * C, ldw = 512, b1 = r * r, b2 = b1 + t * r, L = b2 + t * r;
+    printf("chain of %d dependent convs [%d x %d, K = %d] (r %d t %d), distinct weights %.1f MB each (%.0f MB in all), GroupNorm + SiLU between ops\n", nops, L, N, K, r, t,
+           K * N * 4e-6, nops * K * N * 4e-6);
+    std::vector<float> W((size_t)K * ldw), ones(C, 1.0f), zeros(C, 0.f), x((size_t)L * C);
+    const float wsc = 1.0f / sqrtf((float)K);
+    for (auto& v : x) v = frand();
+    std::vector<float*> dW(nops), dWd(nops);
+    float *gamma = dup(ones), *beta = dup(zeros), *bias = dup(zeros);
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    // ---- legacy chain: k_conv with the tile of the product's plan (t1,2,8,8x at 32 tokens, t1,4,8,4x at 128), statistics by epilogue atomics
+    CK(conv_init_attrs());
+    CK(deep_init_attrs());
+    std::vector<int> g((size_t)9 * L, -1);
+    for (int tok = 0; tok < L; ++tok)
+        for (int tap = 0; tap < 9; ++tap) { const int gg = geo_source(r, t, tok, tap / 3, tap % 3, false); g[(size_t)tap * L + tok] = gg < 0 ? -1 : (gg & 0x0FFFFFFF); }
+    int* dg = dnew<int>(g.size());
+    CK(hipMemcpy(dg, g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    for (int o = 0; o < nops; ++o) {
+        for (auto& v : W) v = frand() * wsc;
+        dW[o] = dup(W);
+    }
+    float* actA[2] = {dup(x), dnew<float>((size_t)L * C)};
+    double* sites = dnew<double>((size_t)(nops + 1) * STAT_COPIES * 192);
+    const unsigned cstride = (unsigned)((nops + 1) * 192);
+    float* slab = dnew<float>((size_t)16 * L * N);
+    int* tickets = dnew<int>(1 << 16);
+    const ConvTile tile = L <= 32 ? ConvTile{1, 2, 8, 8, 1} : ConvTile{1, 4, 8, 4, 1};
+    std::vector<ConvArgs> ca(nops);
+    for (int o = 0; o < nops; ++o) {
+        ConvArgs a{};
+        a.src[0] = actA[o & 1]; a.C[0] = C; a.nmain = 1; a.Cmain = C; a.gather = dg; a.ntaps = 9; a.Lout = L; a.Lsrc = L; a.Lskip = L; a.B = 1;
+        a.W = dW[o]; a.ldw = ldw; a.N = N; a.bias = bias; a.out = actA[(o + 1) & 1];
+        a.seg_src = SegInfo{b1, b2, L}; a.seg_out = a.seg_src; a.slab = slab; a.tickets = tickets;
+        a.geo_main = 1; a.geo_r = r; a.geo_t = t;
+        a.gn = GnIn{sites + (size_t)o * 192, gamma, beta, nullptr, 0, C / 32, 0, 1, cstride};
+        a.gn.inv_gs = 1.0f / (C / 32);
+        a.gn.inv_n[0] = 1.0 / ((double)b1 * (C / 32)); a.gn.inv_n[1] = 1.0 / ((double)(b2 - b1) * (C / 32)); a.gn.inv_n[2] = 1.0 / ((double)(L - b2) * (C / 32)); a.gn.inv_n[3] = 1.0 / ((double)L * (C / 32));
+        a.stat[0] = StatOut{sites + (size_t)(o + 1) * 192, C / 32, 0, 1.0f / (C / 32)};
+        a.nstat = 1; a.stat_cstride = cstride;
+        ca[o] = a;
+    }
+    auto time_graph = [&](const char* name, std::function<void()> body, int reps) {
+        hipGraph_t gr; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        body();
+        CK(hipStreamEndCapture(s, &gr));
+        CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, s));
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        printf("  %-34s %9.2f us per chain  %7.2f us per op  %6.2f TB/s of weights  (%.2f us per 10 ops)\n", name, us, us / nops, nops * K * N * 4e-6 / us, 10 * us / nops);
+        return us;
+    };
+    // statistics of the chain input (site 0): computed once on the host so that op 0 normalises like the others
+    {
+        std::vector<double> hs(192, 0.0);
+        for (int tok = 0; tok < L; ++tok)
+            for (int ch = 0; ch < C; ++ch) { const int p = tok >= b2 ? 2 : (tok >= b1 ? 1 : 0); const double v = x[(size_t)tok * C + ch]; hs[(p * 32 + ch / 16) * 2] += v; hs[(p * 32 + ch / 16) * 2 + 1] += v * v; }
+        CK(hipMemcpy(sites, hs.data(), 192 * 8, hipMemcpyHostToDevice));
+    }
+    const double t_old = time_graph("k_conv chain (product tile)", [&]() {
+        CK(hipMemsetAsync(sites + 192, 0, (size_t)((nops + 1) * STAT_COPIES * 192 - 192) * 8, s));     // (one memset per chain: the product zeroes in the head conv)
+        for (int o = 0; o < nops; ++o) CK(launch_conv(ca[o], tile, s));
+    }, 30);
+    // ---- deep chain
+    std::vector<DeepArgs> da(nops);
+    const int KS = ks_arg ? ks_arg : (L <= 32 ? 8 : 4), nrg = nrg_arg ? nrg_arg : (L <= 32 ? 1 : 2);
+    printf("  deep: KS %d nrg %d\n", KS, nrg);
+    float* slabs[2] = {dnew<float>((size_t)8 * L * C), dnew<float>((size_t)8 * L * C)};
+    float* zeros_d = dnew<float>(2 * C);
+    CK(hipMemcpy(slabs[0], x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    DeepTile tl{};
+    for (int o = 0; o < nops; ++o) {
+        DeepArgs a{};
+        a.main[0] = DeepSrc{slabs[o & 1], (unsigned)((size_t)L * C), o == 0 ? 1 : KS, C};
+        a.Cmain = C; a.ntaps = 9; a.r = r; a.t = t; a.B = 1; a.Lout = L; a.Lsrc = L; a.Lres = L; a.N = N;
+        a.bias = bias; a.gamma = gamma; a.beta = beta; a.gs = C / 32; a.gn = 1; a.act = 1;
+        a.out = slabs[(o + 1) & 1]; a.out_slab_stride = (unsigned)((size_t)L * N);
+        a.KS = KS; a.CSm = C / KS; a.nrg = nrg;
+        a.zeros = zeros_d;
+        if (!deep_tile_for(a, &tl)) { printf("no tile\n"); exit(1); }
+        a.tiles_n = N / (16 * tl.NT);
+        dWd[o] = dnew<float>((size_t)K * N);
+        CK(launch_deep_repack(dW[o], ldw, dWd[o], a, tl.NT, 0));
+        a.W = dWd[o];
+#ifdef MTV_DEEP_STAMP
+        if (o == nops / 2) a.dbg = dnew<unsigned long long>(64);
+#endif
+        da[o] = a;
+    }
+    CK(hipDeviceSynchronize());
+    {   // the two chains compute the same function: compare after 2 ops (40 chaotic layers amplify rounding differences to O(1))
+        CK(hipMemcpy(slabs[0], x.data(), x.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(actA[0], x.data(), x.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemsetAsync(sites + 192, 0, (size_t)((nops + 1) * STAT_COPIES * 192 - 192) * 8, s));
+        for (int o = 0; o < 2; ++o) { CK(launch_conv(ca[o], tile, s)); CK(launch_deep_conv(da[o], tl, s)); }
+        CK(hipStreamSynchronize(s));
+        std::vector<float> a1((size_t)L * C), a2((size_t)KS * L * C);
+        CK(hipMemcpy(a1.data(), actA[0], a1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(a2.data(), slabs[0], a2.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0, sc = 0;
+        for (size_t e = 0; e < a1.size(); ++e) {
+            float v = 0;
+            for (int k = 0; k < KS; ++k) v += a2[(size_t)k * a1.size() + e];
+            worst = std::max(worst, (double)fabsf(v - a1[e]));
+            sc = std::max(sc, (double)fabsf(a1[e]));
+        }
+        printf("  after 2 ops, k_conv vs k_deep_conv: max|diff| %.3e (|x| <= %.2f)\n", worst, sc);
+        CK(hipMemcpy(slabs[0], x.data(), x.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(actA[0], x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    }
+    const double t_new = time_graph("k_deep_conv chain", [&]() { for (int o = 0; o < nops; ++o) CK(launch_deep_conv(da[o], tl, s)); }, 30);
+    printf("  ratio k_conv / k_deep_conv = %.2fx\n", t_old / t_new);
+#ifdef MTV_DEEP_STAMP
+    {
+        unsigned long long h[64];
+        CK(hipMemcpy(h, da[nops / 2].dbg, sizeof h, hipMemcpyDeviceToHost));
+        static const char* nm[16] = {"entry", "decoded", "stats added", "barrier 1", "transformed+barrier", "mfma done", "barrier", "end", "tables built", "main staged", "skip staged", "-", "slabs issued", "weights issued", "barrier 0", "first group done"};
+        static const int order[2][16] = {{1, 12, 13, 8, 14, 9, 10, 2, 3, 4, 15, 5, 6, 7, -1}, {1, 12, 13, 8, 14, 9, 10, 2, 3, 4, 15, 5, 6, 7, -1}};
+        for (int blk = 0; blk < 2; ++blk)
+            for (int role = 0; role < 2; ++role) {
+                printf("  stamps op %d wg %s %s (cycles since entry):", nops / 2, blk ? "mid" : "0", role ? "wave 4" : "wave 0");
+                for (int k = 0; order[role][k] >= 0; ++k) printf("  %s %lld", nm[order[role][k]], (long long)(h[blk * 32 + role * 16 + order[role][k]] - h[blk * 32 + role * 16]));
+                printf("\n");
+            }
+    }
+#endif
+    // the two chains compute the same function of the same input: compare the final activations
+    {
+        std::vector<float> a1((size_t)L * C), a2((size_t)KS * L * C);
+        CK(hipMemcpy(a1.data(), actA[nops & 1], a1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(a2.data(), slabs[nops & 1], a2.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0, sc = 0;
+        for (size_t e = 0; e < a1.size(); ++e) {
+            float v = 0;
+            for (int k = 0; k < KS; ++k) v += a2[(size_t)k * a1.size() + e];
+            worst = std::max(worst, (double)fabsf(v - a1[e]));
+            sc = std::max(sc, (double)fabsf(a1[e]));
+        }
+        printf("  final activations of the two chains: max|diff| %.3e (|x| <= %.2f)\n", worst, sc);
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 2 && !strcmp(argv[1], "check")) { CK(deep_init_attrs()); return do_check(); }
+    if (argc >= 2 && !strcmp(argv[1], "chain")) {
+        const int nops = argc >= 3 ? atoi(argv[2]) : 40;
+        const int r = argc >= 5 ? atoi(argv[3]) : 4, t = argc >= 5 ? atoi(argv[4]) : 2;
+        do_chain(nops, r, t, argc >= 6 ? atoi(argv[5]) : 0, argc >= 7 ? atoi(argv[6]) : 0);
+        return 0;
+    }
+    printf("usage: deep_bench check | chain [nops] [r t]\n");
+    return 1;
+}
