@@ -56,9 +56,15 @@ __device__ __forceinline__ f32x4 slab_fold(const f32x4 (&v)[KSI]) {
     for (int k = 1; k < KSI; ++k) s += v[k];
     return s;
 }
-__device__ __forceinline__ f32x4 slab_sum_rt(const float* p, unsigned stride, int ks) {     // run-time slab count (epilogue residual)
-    f32x4 s = *reinterpret_cast<const f32x4*>(p);
-    for (int k = 1; k < ks; ++k) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
+__device__ __forceinline__ f32x4 slab_sum_rt(const float* p, unsigned stride, int ks) {     // run-time slab count <= 8 (epilogue residual)
+    if (ks == 1) return *reinterpret_cast<const f32x4*>(p);
+    f32x4 t[8];                                               // all eight requested at once (absent slabs re-read slab 0): a loop that
+#pragma unroll                                                // adds as it goes waits a full round trip per slab
+    for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(p + (size_t)(k < ks ? k : 0) * stride);
+    f32x4 s = t[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < ks) s += t[k];                                // slab order
     return s;
 }
 
@@ -546,6 +552,235 @@ __global__ __launch_bounds__(128) void k_deep_finalize(const DeepFinArgs a) {
     }
 }
 
+
+// =====================================================================================
+// attention core + proj_out at <= 128 tokens
+// =====================================================================================
+__device__ __forceinline__ float deep_swap_max16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float deep_swap_max32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// 512 threads = 8 waves = 2 query tiles (16 queries) x 4 key parts.  Per head of the group: K rows, V^T and Q go to LDS (q and k
+// scaled by d^-1/4, q also by log2 e: scores in the log2 domain), each wave computes S^T = K Q^T for its key tiles (a query is a
+// lane COLUMN: softmax reductions are register values + two lane swaps; the P^T registers are the B operand of
+// O^T += V^T P^T, as in k_attention), the four key parts of a query tile are merged through LDS into the normalised output
+// rows.  Then D = attention rows x Wp[head group rows][column group] on the same MFMA, K split over the waves, summed in LDS.
+template <int D>
+__global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
+    touch_kernargs<(int)sizeof(DeepAttnArgs)>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr float LOG2E = 1.4426950408889634f;
+    constexpr int KSTR = D + 4, NDT = D / 16, QPR = D / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = deep_usgpr(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int blk = deep_usgpr((int)blockIdx.x);
+    const int cg = deep_usgpr(FDiv{a.inv_nslots}(blk, a.nslots));
+    const int slot = blk - cg * a.nslots;
+    const int hg = slot % a.nhg;
+    const int rest = slot / a.nhg;
+    const int qg = rest % a.nqg, b = rest / a.nqg;
+    const int q0 = qg * 32;
+    const int L = a.L, C = a.C, HPW = a.HPW, NC = a.NC;
+    const int b1 = a.r * a.r, b2 = b1 + a.t * a.r;
+    // keys this query group can see: all (whole) or the planes its queries live in
+    int k0 = 0, k1 = L;
+    if (!a.whole) {
+        const int qlast = (q0 + 32 < L ? q0 + 32 : L) - 1;
+        k0 = q0 >= b2 ? b2 : (q0 >= b1 ? b1 : 0);
+        k1 = qlast >= b2 ? L : (qlast >= b1 ? b2 : b1);
+    }
+    const int nk = k1 - k0, nkt = (nk + 15) >> 4;
+    const int VSTR = a.kcap + 4, AS = HPW * D + 8, WS = HPW * D + 4;
+    float* const Ks = smem;                                   // [kcap][KSTR]
+    float* const Vt = Ks + a.kcap * KSTR;                     // [D][VSTR]
+    float* const Qs = Vt + D * VSTR;                          // [32][KSTR]
+    float* const Att = Qs + 32 * KSTR;                        // [32][AS]: normalised attention rows of the head group
+    float* const Wt = Att + 32 * AS;                          // [NC][WS]: proj slice, transposed (k contiguous)
+    float* const Os = Wt + NC * WS;                           // [8 waves][16 queries][D + 4]: key-part partials (then proj partials)
+    float* const ml = Os + 8 * 16 * (D + 4);                  // [8 waves][16 queries][2]: (m, l) of the key parts
+    const int qt = wave & 1, kp = wave >> 1;                  // this wave: query tile, key part
+    // ---- proj slice requested first: it depends on nothing (held in registers until the first barrier)
+    const int kw = HPW * D, wq = NC >> 2;                     // K rows of the slice, column quads
+    f32x4 wreg[2];
+    {
+        const float* wb = a.Wp + (size_t)(hg * kw) * a.ldw + cg * NC;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + DEEP_NTH * u;
+            const int kr = e / wq, cq = e - kr * wq;
+            wreg[u] = *reinterpret_cast<const f32x4*>(wb + (size_t)(kr < kw ? kr : 0) * a.ldw + 4 * cq);
+        }
+    }
+    for (int hh = 0; hh < HPW; ++hh) {
+        const int h = hg * HPW + hh;
+        const float* base = a.qkv + (size_t)b * L * 3 * C + (size_t)h * 3 * D;
+        // ---- stage K (scaled), V^T and Q (scaled, log2 domain); rows past the last key of a tile are zero
+        for (int e = tid; e < nkt * 16 * QPR; e += DEEP_NTH) {
+            const int key = e / QPR, qd = e - key * QPR;
+            const bool in = key < nk;
+            const float* p = base + (size_t)(k0 + (in ? key : 0)) * 3 * C + D + 4 * qd;
+            f32x4 kv = *reinterpret_cast<const f32x4*>(p);
+            f32x4 vv = *reinterpret_cast<const f32x4*>(p + D);
+            if (!in) { kv = f32x4{0.f, 0.f, 0.f, 0.f}; vv = kv; }
+            *reinterpret_cast<f32x4*>(Ks + key * KSTR + 4 * qd) = kv * a.scale;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Vt[(4 * qd + c) * VSTR + key] = vv[c];
+        }
+        for (int e = tid; e < 32 * QPR; e += DEEP_NTH) {
+            const int qr = e / QPR, qd = e - qr * QPR;
+            const int tok = q0 + qr;
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(base + (size_t)(tok < L ? tok : 0) * 3 * C + 4 * qd);
+            *reinterpret_cast<f32x4*>(Qs + qr * KSTR + 4 * qd) = qv * (a.scale * LOG2E);
+        }
+        if (hh == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + DEEP_NTH * u;
+                const int kr = e / wq, cq = e - kr * wq;
+                if (kr < kw) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Wt[(4 * cq + c) * WS + kr] = wreg[u][c];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- this wave: query tile qt, key tiles kp, kp + 4 (nkt <= 8)
+        float qreg[NDT][4];
+#pragma unroll
+        for (int u = 0; u < NDT; ++u) {
+            const f32x4 tq = *reinterpret_cast<const f32x4*>(Qs + (16 * qt + j) * KSTR + 16 * u + 4 * g);
+            qreg[u][0] = tq[0]; qreg[u][1] = tq[1]; qreg[u][2] = tq[2]; qreg[u][3] = tq[3];
+        }
+        const int qtok = q0 + 16 * qt + j;                     // this lane's query (column j)
+        const int qpl = qtok >= b2 ? 2 : (qtok >= b1 ? 1 : 0);
+        f32x4 st[2];
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int kt = kp + 4 * w;
+            f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+#pragma unroll
+                for (int u = 0; u < NDT; ++u) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + j) * KSTR + 16 * u + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qreg[u][e], sacc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int key = k0 + 16 * kt + 4 * g + rr;
+                const int kpl = key >= b2 ? 2 : (key >= b1 ? 1 : 0);
+                const bool dead = kt >= nkt || key >= k1 || (!a.whole && kpl != qpl);
+                sacc[rr] = dead ? -INFINITY : sacc[rr];
+                m = fmaxf(m, sacc[rr]);
+            }
+            st[w] = sacc;
+        }
+        m = deep_swap_max16(m);
+        m = deep_swap_max32(m);
+        const bool live = m != -INFINITY;                    // (a key part may hold only keys of other planes)
+        float lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float pz = live ? __builtin_amdgcn_exp2f(st[w][rr] - m) : 0.f;
+                st[w][rr] = pz;
+                lsum += pz;
+            }
+        lsum += __shfl_xor(lsum, 16);
+        lsum += __shfl_xor(lsum, 32);
+        f32x4 oacc[NDT];
+#pragma unroll
+        for (int o = 0; o < NDT; ++o) oacc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int kt = kp + 4 * w;
+            if (kt < nkt) {
+#pragma unroll
+                for (int o = 0; o < NDT; ++o) {
+                    const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (16 * o + j) * VSTR + 16 * kt + 4 * g);
+#pragma unroll
+                    for (int sI = 0; sI < 4; ++sI) oacc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[sI], st[w][sI], oacc[o], 0, 0, 0);
+                }
+            }
+        }
+        // park (m, l, O^T) of this key part: O^T lane (query j, group g) reg r = d index 16 o + 4 g + r
+        {
+            float* op = Os + ((size_t)wave * 16 + j) * (D + 4) + 4 * g;
+#pragma unroll
+            for (int o = 0; o < NDT; ++o) *reinterpret_cast<f32x4*>(op + 16 * o) = oacc[o];
+            if (g == 0) { ml[(wave * 16 + j) * 2] = m; ml[(wave * 16 + j) * 2 + 1] = lsum; }
+        }
+        __syncthreads();
+        // ---- merge the four key parts of every query: thread -> (query row, d quad)
+        for (int e = tid; e < 32 * QPR; e += DEEP_NTH) {
+            const int qr = e / QPR, dq = e - qr * QPR;
+            const int tq = qr >> 4, jq = qr & 15;
+            float mm[4], ll[4], M = -INFINITY;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const int w = tq + 2 * k2;
+                mm[k2] = ml[(w * 16 + jq) * 2];
+                ll[k2] = ml[(w * 16 + jq) * 2 + 1];
+                M = fmaxf(M, mm[k2]);
+            }
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            float lt = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const int w = tq + 2 * k2;
+                const float f = mm[k2] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mm[k2] - M);
+                lt += ll[k2] * f;
+                o += *reinterpret_cast<const f32x4*>(Os + ((size_t)w * 16 + jq) * (D + 4) + 4 * dq) * f;
+            }
+            *reinterpret_cast<f32x4*>(Att + qr * AS + hh * D + 4 * dq) = o * (1.0f / lt);
+        }
+        __syncthreads();
+    }
+    // ---- proj: [32 rows][NC cols] = Att [32][kw] x Wt^T; wave -> (tile, K part)
+    const int nct = NC >> 4, ntile = 2 * nct, kparts = 8 / ntile;       // (ntile 2 or 4)
+    const int tile = wave % ntile, kpart = wave / ntile;
+    const int rt = tile & 1, ct = tile >> 1;
+    const int kchunks = kw >> 4, cpp = (kchunks + kparts - 1) / kparts;  // 16-channel chunks per K part
+    f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+    for (int cc = kpart * cpp; cc < (kpart + 1) * cpp && cc < kchunks; ++cc) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(Att + (16 * rt + j) * AS + 16 * cc + 4 * g);
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(Wt + (16 * ct + j) * WS + 16 * cc + 4 * g);
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[sI], bf[sI], pacc, 0, 0, 0);
+    }
+    {   // D lane (col j, group g) reg r = row 4 g + r -> [wave][row][col]
+        float* pp = Os + (size_t)wave * 16 * 20 + (4 * g) * 20 + j;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) pp[rr * 20] = pacc[rr];
+    }
+    __syncthreads();
+    // epilogue: thread -> (row, column quad); K parts summed in order; head group 0 adds bias + residual
+    for (int e = tid; e < 32 * (NC >> 2); e += DEEP_NTH) {
+        const int rr = e / (NC >> 2), cq = e - rr * (NC >> 2);
+        const int tok = q0 + rr;
+        if (tok >= L) continue;
+        const int t2 = (rr >> 4) + 2 * ((4 * cq) >> 4);        // tile of this quad
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int k2 = 0; k2 < kparts; ++k2)
+            v += *reinterpret_cast<const f32x4*>(Os + (size_t)(t2 + ntile * k2) * 16 * 20 + (rr & 15) * 20 + ((4 * cq) & 15));
+        const int n = cg * NC + 4 * cq;
+        if (hg == 0) {
+            v += *reinterpret_cast<const f32x4*>(a.bias + n);
+            v += slab_sum_rt(a.res.p + ((size_t)b * L + tok) * a.res.C + n, a.res.slab_stride, a.res.ks);
+        }
+        *reinterpret_cast<f32x4*>(a.out + (size_t)hg * a.out_slab_stride + ((size_t)b * L + tok) * C + n) = v;
+    }
+}
+
 // =====================================================================================
 // host side
 // =====================================================================================
@@ -688,6 +923,11 @@ hipError_t deep_init_attrs() {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
+    const void* fa[] = {reinterpret_cast<const void*>(&k_deep_attn<16>), reinterpret_cast<const void*>(&k_deep_attn<32>), reinterpret_cast<const void*>(&k_deep_attn<64>)};
+    for (const void* f : fa) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 
@@ -698,6 +938,56 @@ hipError_t launch_deep_repack(const float* W, int ldw, float* dst, const DeepArg
     a.nch = a.nmain_ch + (a.Cskip ? a.CSs / 16 : 0);
     const long total = (long)deep_weight_floats(a, NT);
     hipLaunchKernelGGL(k_deep_repack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, ldw, dst, a, NT, total);
+    return hipGetLastError();
+}
+
+
+static size_t deep_attn_smem(const DeepAttnArgs& a, int D) {
+    const int KSTR = D + 4, VSTR = a.kcap + 4, AS = a.HPW * D + 8, WS = a.HPW * D + 4;
+    return (size_t)(a.kcap * KSTR + D * VSTR + 32 * KSTR + 32 * AS + a.NC * WS + 8 * 16 * (D + 4) + 8 * 16 * 2) * 4;
+}
+
+bool deep_attn_configure(DeepAttnArgs& a) {
+    if (a.H < 1 || a.C % a.H || a.L < 1 || a.L > 128 || (a.C & 15)) return false;
+    const int d = a.C / a.H;
+    if (d != 16 && d != 32 && d != 64) return false;
+    a.kcap = (a.L + 15) / 16 * 16;
+    a.nqg = (a.L + 31) / 32;
+    // head group = K slice of the projection = an output slab: as few slabs as the grid allows (consumers re-read every slab)
+    for (int hpw : {8, 4, 2, 1}) {
+        if (a.H % hpw || hpw * d > 128) continue;
+        for (int nc : {32, 16}) {
+            if (a.C % nc) continue;
+            if ((hpw * d) * (nc / 4) > 2 * DEEP_NTH) continue;             // proj slice: two 16-byte quads per thread
+            a.HPW = hpw; a.NC = nc; a.nhg = a.H / hpw; a.ncg = a.C / nc;
+            if (a.nhg > 8 || (a.nhg & (a.nhg - 1))) continue;
+            if (deep_attn_smem(a, d) > 160 * 1024) continue;
+            const long wgs = (long)a.B * a.nqg * a.nhg * a.ncg;
+            if (wgs >= 128) return true;                                     // enough to occupy half the chip: take the fewest slabs
+        }
+    }
+    // small models: anything that fits
+    for (int hpw : {1, 2, 4, 8}) {
+        if (a.H % hpw || hpw * d > 128) continue;
+        a.HPW = hpw; a.NC = 16; a.nhg = a.H / hpw; a.ncg = a.C / 16;
+        if (a.nhg > 8 || (a.nhg & (a.nhg - 1)) || (hpw * d) * 4 > 2 * DEEP_NTH) continue;
+        if (deep_attn_smem(a, d) <= 160 * 1024) return true;
+    }
+    return false;
+}
+
+hipError_t launch_deep_attn(const DeepAttnArgs& a0, hipStream_t s) {
+    DeepAttnArgs a = a0;
+    const int d = a.C / a.H;
+    a.nslots = a.B * a.nqg * a.nhg;
+    a.inv_nslots = 1.0f / (float)a.nslots;
+    const size_t smem = deep_attn_smem(a, d);
+    if (smem > 160 * 1024 || (a.NC != 16 && a.NC != 32) || !(a.res.ks >= 1 && a.res.ks <= 8)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(a.ncg * a.nslots));
+    if (d == 16) hipLaunchKernelGGL((k_deep_attn<16>), grid, dim3(DEEP_NTH), smem, s, a);
+    else if (d == 32) hipLaunchKernelGGL((k_deep_attn<32>), grid, dim3(DEEP_NTH), smem, s, a);
+    else if (d == 64) hipLaunchKernelGGL((k_deep_attn<64>), grid, dim3(DEEP_NTH), smem, s, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

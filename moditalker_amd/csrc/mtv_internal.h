@@ -294,6 +294,28 @@ struct DeepFinArgs {
     unsigned stat_cstride;
 };
 
+// QKVAttentionLegacy core + proj_out of one attention block at <= 128 tokens (deep.hip, k_deep_attn): a workgroup = (clip, head
+// group, 32 queries, column group) computes the attention of its heads for its queries and multiplies it by its slice of the
+// proj_out matrix: the head group IS the K slice of the projection, its partial result goes to slab `head group`.
+struct DeepAttnArgs {
+    const float* qkv;        // plain [B][L][3C], channel = head * 3d + {q: 0.., k: d.., v: 2d..}  (unet.py:312-326)
+    int B, L, C, H;
+    int r, t;                // plane geometry of the level
+    int whole;               // 1: every query sees all L keys (AttentionBlock1D); 0: the keys of its own plane
+    float scale;             // d^-1/4, applied to q and to k
+    const float* Wp;         // proj_out as k_conv stores it: [C rows = input channel][ldw], columns = output channel
+    int ldw;
+    const float* bias;       // [C]
+    DeepSrc res;             // the block's input x (residual), possibly slabs
+    float* out;              // slab 0 of [H / HPW][B][L][C]
+    unsigned out_slab_stride;
+    int HPW, NC;             // heads per workgroup (K slice = HPW d channels), output columns per workgroup (16 or 32)
+    int nhg, nqg, ncg;       // head groups, query groups (32 rows), column groups
+    int kcap;                // key capacity of the LDS tiles: 16 ceil(L / 16)
+    float inv_nslots;
+    int nslots;              // B * nqg * nhg
+};
+
 struct LinearArgs {
     const float* x;          // [B][K]
     const float* W;          // [N][K]
@@ -363,6 +385,8 @@ size_t deep_smem_bytes(const DeepArgs& a, DeepTile t);
 hipError_t launch_deep_conv(const DeepArgs& a, DeepTile t, hipStream_t s);
 hipError_t launch_deep_repack(const float* W, int ldw, float* dst, const DeepArgs& a, int NT, hipStream_t s);   // legacy [krow][ldw] -> deep layout
 hipError_t launch_deep_finalize(const DeepFinArgs& a, hipStream_t s);
+bool deep_attn_configure(DeepAttnArgs& a);                // fills HPW / NC / group counts; false: this block keeps k_attention + a proj conv
+hipError_t launch_deep_attn(const DeepAttnArgs& a, hipStream_t s);
 hipError_t deep_init_attrs();
 hipError_t launch_linear(const LinearArgs& a, hipStream_t s);
 hipError_t launch_time_sinusoid(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);

@@ -687,7 +687,50 @@ struct Builder {
         c->slots[c->slot_index[P + "proj_out.weight"]].dst2 = Wp_nk;
         float* bp = c->wcopy(P + "proj_out.bias", {C});
 
-        if (deep_on(lvl)) {
+        // ---- deep level (deep.hip): attention core + proj_out in ONE launch (k_deep_attn; the head groups are the K slices of the
+        // projection, one output slab each).  It reads every channel of a head, so qkv must be one plain tensor: by default the
+        // block's input is summed up once (k_deep_finalize, which also leaves the GroupNorm statistics) and qkv stays on k_conv
+        // -- a K-sliced qkv conv (MTV_DEEP_QKV=1) stages ALL tokens of its channel slice per column tile and then needs its own
+        // finalize pass: measured slower at both deep levels.
+        DeepAttnArgs da{};
+        da.B = B; da.L = L.L; da.C = C; da.H = H; da.r = L.r; da.t = L.t; da.whole = whole ? 1 : 0;
+        da.scale = 1.0f / std::sqrt(std::sqrt((float)d));
+        da.Wp = Wp; da.ldw = ldp; da.bias = bp;
+        static const bool fuse_env = []() { const char* e = getenv("MTV_DEEP_ATTN"); return !e || atoi(e) != 0; }();
+        static const bool deep_qkv_env = []() { const char* e = getenv("MTV_DEEP_QKV"); return e && atoi(e) != 0; }();
+        const bool fused = deep_on(lvl) && fuse_env && deep_attn_configure(da);
+        auto emit_fused = [&](const float* qkv_plain, const Tens& xres) -> Tens {
+            Tens out;
+            out.lvl = lvl; out.C = C; out.ks = da.nhg;
+            out.slab = (unsigned)((size_t)c->cfg.max_batch * L.L * C);
+            out.p = c->buf("act.deep." + nm + ".out", (size_t)8 * out.slab);
+            if (!out.p) { err = "deep attention allocation failed at " + nm; return Tens{}; }
+            c->taps[nm + ".out"] = {lvl, C};
+            c->bufs["tap." + nm + ".out"] = out.p;
+            c->tap_slabs[nm + ".out"] = {out.ks, out.slab};
+            da.qkv = qkv_plain;
+            da.res = dsrc(xres);
+            da.out = out.p;
+            da.out_slab_stride = out.slab;
+            double aflops = 0.0;
+            {
+                const int segs[3] = {L.b1, L.b2 - L.b1, L.L - L.b2};
+                if (whole) aflops = 4.0 * B * H * (double)L.L * L.L * d;
+                else for (int sg : segs) aflops += 4.0 * B * H * (double)sg * sg * d;
+            }
+            if (c->accounting) {
+                c->work.flops_attn_core += aflops / B;
+                c->work.flops_1x1 += 2.0 * (double)L.L * C * C;
+                c->work.bytes_weights_other += 4.0 * (double)C * C + 4.0 * C;
+            }
+            char tag[96];
+            snprintf(tag, sizeof tag, "[L%d d%d %s +proj h%d,c%d]", L.L, d, whole ? "1d" : "2d", da.HPW, da.NC);
+            const DeepAttnArgs dac = da;
+            push("attn:" + nm + tag, [dac](hipStream_t s) { return launch_deep_attn(dac, s); }, aflops + 2.0 * B * (double)L.L * C * C,
+                 4.0 * B * L.L * (3.0 * C + 2.0 * C) + 4.0 * (double)C * C);
+            return out;
+        };
+        if (deep_on(lvl) && deep_qkv_env) {
             DeepArgs dq = deep_args(lvl, 1, 3 * C, bq);
             dq.Cmain = C;
             dq.main[0] = dsrc(x0);
@@ -697,11 +740,12 @@ struct Builder {
             dp.main[0] = DeepSrc{dp.zeros, 0, 1, C};                       // (placeholder for the attention output)
             dp.res = dsrc(x0);
             DeepTile tq{}, tp{};
-            if (deep_configure(dq, &tq) && deep_configure(dp, &tp)) {
+            if (deep_configure(dq, &tq) && (fused || deep_configure(dp, &tp))) {
                 const Tens qkvd = emit_deep(dq, tq, Wq, ldq, nm + ".qkv", lvl);
                 if (!err.empty()) return Tens{};
+                const Tens qkvp = materialize(qkvd, nm + ".qkv");
+                if (fused) return emit_fused(qkvp.p, x0);
                 float* attd = c->act(nm + ".att", lvl, C);
-                const Tens qkvp = materialize(qkvd, nm + ".qkv");         // (k_attention adds slabs through a serial loop: plain input instead)
                 AttnArgs t = attn_args(qkvp.p, attd, L, C, H, d, whole);
                 push_attention(t, nm, L, C, d, whole);
                 Tens ad;
@@ -719,6 +763,7 @@ struct Builder {
         a.nmain = 1; a.src[0] = x.p; a.C[0] = C; a.Cmain = C; a.seg_src = L.seg();
         a.gn = GnIn{site, gw, gb, nullptr, 0, C / 32, whole ? 1 : 0, 0, (unsigned)c->stats_copy_doubles};
         add_conv(a, nm + ".qkv", lvl);
+        if (fused) return emit_fused(qkv, x);
 
         float* att = c->act(nm + ".att", lvl, C);
         push_attention(attn_args(qkv, att, L, C, H, d, whole), nm, L, C, d, whole);
