@@ -26,6 +26,8 @@
 // W[c0 + 4q .. + 3][n0 + j] (one 16-byte global load, lane-linear in the repacked matrix), MFMA step s consumes component s.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <vector>
 
 #include "mtv_internal.h"
 
@@ -190,6 +192,17 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
     double* const sdp = reinterpret_cast<double*>(smem + a.lds_stat);     // [3 planes][DEEP_MAX_NG][2]: (sum, sum of squares) of the slice
     const int nch = a.nch;
     DEEP_STAMP(1);
+    // the row table of this row group -- [ntaps][ROWS] float offsets into the staged main slice (zero row = padding), then [ROWS] into
+    // the skip slice -- comes from the host (deep_rowtab): requested before anything else, parked in LDS once the weights are on their way
+    int treg[3];
+    {
+        const int* tb = a.rowtab + rg * ((a.ntaps + 1) * ROWS);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = tid + DEEP_NTH * u;
+            treg[u] = tb[e < (a.ntaps + 1) * ROWS ? e : 0];
+        }
+    }
 
     // =========================================================================================================== phase 0
     // request order per wave: activation slice (first pass) -> GroupNorm vectors -> weights; then the row table while they fly
@@ -229,25 +242,12 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
         wload(bq[0], 0);
         wload(bq[1], G);
         DEEP_STAMP(13);
-        // row table, zero rows, statistics slots: LDS work under the loads
-        for (int e = tid; e < a.ntaps * ROWS; e += DEEP_NTH) {
-            const int tap = e / ROWS, ri = e - tap * ROWS;
-            const int tok = rg_tok0 + ri;
-            int row = -1;
-            if (ri < rg_ntok) {
-                if (a.ntaps == 9) {
-                    const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
-                    const int g = geo_source_t<FDiv>(FDiv{a.inv_r}, r, t, tok, ky, tap - 3 * ky, a.up_main != 0);
-                    row = g < 0 ? -1 : (g & 0x0FFFFFFF) - src_tok0;
-                } else if (a.up_main) {
-                    row = (geo_source_t<FDiv>(FDiv{a.inv_r}, r, t, tok, 1, 1, true) & 0x0FFFFFFF) - src_tok0;
-                } else {
-                    row = tok - src_tok0;
-                }
-            }
-            idx[e] = row < 0 ? zoff_main : row * SM;
+        // row table (precomputed on the host, requested first of all: deep_rowtab), zero rows, statistics slots: LDS work under the loads
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = tid + DEEP_NTH * u;
+            if (e < (a.ntaps + 1) * ROWS) idx[e] = treg[u];
         }
-        for (int e = tid; e < ROWS; e += DEEP_NTH) idx[a.ntaps * ROWS + e] = e < rg_ntok ? e * SS : ROWS * SS;
         for (int e = tid; e < a.CSm; e += DEEP_NTH) lmain[zoff_main + e] = 0.f;
         if (a.Cskip)
             for (int e = tid; e < a.CSs; e += DEEP_NTH) lskip[ROWS * SS + e] = 0.f;
@@ -281,12 +281,32 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
     if (a.gn) {
         // per-thread partial sums -> the slice's (plane, group) slots.  Quads of one group sit in adjacent lanes: fold them first
         // (2 DPP-free shuffles would cost more than the contention they save at gs <= 16: plain LDS fp64 atomics)
+        // the gs / 4 quads of a group sit in adjacent lanes: fold pairs / quads of lanes first (DPP quad permutes: VALU, no LDS)
+        const int gq = a.gs >> 2;
+        auto dpp_add = [](double v, auto ctrl) -> double {
+            constexpr int CTRL = decltype(ctrl)::value;
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+            const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
+            const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
+            return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        };
+        if (gq >= 2) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            if (acc[2 * p + 1] != 0.0) {
-                atomicAdd(&sdp[(p * DEEP_MAX_NG + gi) * 2], acc[2 * p]);
-                atomicAdd(&sdp[(p * DEEP_MAX_NG + gi) * 2 + 1], acc[2 * p + 1]);
-            }
+            for (int k = 0; k < 6; ++k) acc[k] = dpp_add(acc[k], std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+        }
+        if (gq >= 4) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] = dpp_add(acc[k], std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+        }
+        const int fold = gq >= 4 ? 4 : (gq >= 2 ? 2 : 1);
+        if ((qdm & (fold - 1)) == 0) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                if (acc[2 * p + 1] != 0.0) {
+                    atomicAdd(&sdp[(p * DEEP_MAX_NG + gi) * 2], acc[2 * p]);
+                    atomicAdd(&sdp[(p * DEEP_MAX_NG + gi) * 2 + 1], acc[2 * p + 1]);
+                }
+        }
     }
     DEEP_STAMP(2);
     __syncthreads();
@@ -297,38 +317,36 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
         // applied ONCE per element, in place in LDS (this thread's quad column: coefficients per plane in registers)
         const int RP = DEEP_NTH >> qw_shift;
         const int rl = tid >> qw_shift;
-        f32x4 cA[3], cB[3];
-        double sx[3], sy[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            sx[p] = sdp[(p * DEEP_MAX_NG + gi) * 2];
-            sy[p] = sdp[(p * DEEP_MAX_NG + gi) * 2 + 1];
-        }
-        if (a.whole) {
-            sx[0] = sx[1] = sx[2] = (sx[0] + sx[1]) + sx[2];
-            sy[0] = sy[1] = sy[2] = (sy[0] + sy[1]) + sy[2];
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const double inv_n = a.whole ? a.inv_n[3] : a.inv_n[p];
-            const double mean = sx[p] * inv_n;
-            double var = sy[p] * inv_n - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            const float mu = (float)mean, rstd = 1.0f / sqrtf((float)var + 1e-5f);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float sc = rstd * ga[k];
-                const float bi = be[k] - sc * mu;
-                const float s1 = 1.0f + fsc[k];
-                cA[p][k] = sc * s1;
-                cB[p][k] = fmaf(bi, s1, sh[k]);
-            }
-        }
         const bool act = a.act != 0;
+        int cur_p = -1;
+        f32x4 A = {0.f, 0.f, 0.f, 0.f}, Bc = A;
         for (int row = rl; row < src_ntok; row += RP) {
             const int tk = src_tok0 + row;
-            const bool p2 = tk >= b2s, p1 = tk >= b1s && !p2;
-            const f32x4 A = p2 ? cA[2] : (p1 ? cA[1] : cA[0]), Bc = p2 ? cB[2] : (p1 ? cB[1] : cB[0]);
+            const int p = tk >= b2s ? 2 : (tk >= b1s ? 1 : 0);
+            if (p != cur_p) {                                  // (rows ascend: at most three times, once for most threads)
+                cur_p = p;
+                double sx, sy;
+                if (a.whole) {
+                    sx = (sdp[(0 * DEEP_MAX_NG + gi) * 2] + sdp[(1 * DEEP_MAX_NG + gi) * 2]) + sdp[(2 * DEEP_MAX_NG + gi) * 2];
+                    sy = (sdp[(0 * DEEP_MAX_NG + gi) * 2 + 1] + sdp[(1 * DEEP_MAX_NG + gi) * 2 + 1]) + sdp[(2 * DEEP_MAX_NG + gi) * 2 + 1];
+                } else {
+                    sx = sdp[(p * DEEP_MAX_NG + gi) * 2];
+                    sy = sdp[(p * DEEP_MAX_NG + gi) * 2 + 1];
+                }
+                const double inv_n = a.whole ? a.inv_n[3] : a.inv_n[p];
+                const double mean = sx * inv_n;
+                double var = sy * inv_n - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                const float mu = (float)mean, rstd = 1.0f / sqrtf((float)var + 1e-5f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sc = rstd * ga[k];
+                    const float bi = be[k] - sc * mu;
+                    const float s1 = 1.0f + fsc[k];
+                    A[k] = sc * s1;
+                    Bc[k] = fmaf(bi, s1, sh[k]);
+                }
+            }
             f32x4* cell = reinterpret_cast<f32x4*>(lmain + row * SM + 4 * qdm);
             f32x4 v = *cell;
 #pragma unroll
@@ -617,27 +635,61 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
             wreg[u] = *reinterpret_cast<const f32x4*>(wb + (size_t)(kr < kw ? kr : 0) * a.ldw + 4 * cq);
         }
     }
-    for (int hh = 0; hh < HPW; ++hh) {
-        const int h = hg * HPW + hh;
-        const float* base = a.qkv + (size_t)b * L * 3 * C + (size_t)h * 3 * D;
-        // ---- stage K (scaled), V^T and Q (scaled, log2 domain); rows past the last key of a tile are zero
-        for (int e = tid; e < nkt * 16 * QPR; e += DEEP_NTH) {
-            const int key = e / QPR, qd = e - key * QPR;
-            const bool in = key < nk;
-            const float* p = base + (size_t)(k0 + (in ? key : 0)) * 3 * C + D + 4 * qd;
-            f32x4 kv = *reinterpret_cast<const f32x4*>(p);
-            f32x4 vv = *reinterpret_cast<const f32x4*>(p + D);
-            if (!in) { kv = f32x4{0.f, 0.f, 0.f, 0.f}; vv = kv; }
-            *reinterpret_cast<f32x4*>(Ks + key * KSTR + 4 * qd) = kv * a.scale;
+    // epilogue operands of head group 0 (bias + the block's input as residual): requested now, they land under the attention
+    constexpr int MAXI = (128 * QPR + DEEP_NTH - 1) / DEEP_NTH;        // K/V items (key, quad) per thread at 128 keys
+    const int nq4 = NC >> 2;
+    // (RAW registers, added up in the epilogue: using a loaded value here would make the wave wait before it requests K / V)
+    f32x4 pre_b = {0.f, 0.f, 0.f, 0.f}, pre_r = {0.f, 0.f, 0.f, 0.f};
+    const bool pre_ok = hg == 0 && tid < 32 * nq4 && q0 + tid / nq4 < L;
+    if (pre_ok) {
+        const int rr = tid / nq4, n = cg * NC + 4 * (tid - rr * nq4);
+        pre_b = *reinterpret_cast<const f32x4*>(a.bias + n);
+        pre_r = *reinterpret_cast<const f32x4*>(a.res.p + ((size_t)b * L + q0 + rr) * a.res.C + n);      // slab 0; further slabs in the epilogue
+    }
+    // K / V / Q of a head: global -> registers (issue) -> LDS (park); the next head's are requested while this one is computed
+    f32x4 kreg[MAXI], vreg[MAXI], qregl;
+    const int nitem = nkt * 16 * QPR;
+    auto issue = [&](int hh) {
+        const float* base = a.qkv + (size_t)b * L * 3 * C + (size_t)(hg * HPW + hh) * 3 * D;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) Vt[(4 * qd + c) * VSTR + key] = vv[c];
+        for (int u = 0; u < MAXI; ++u) {
+            const int e = tid + DEEP_NTH * u;
+            if (DEEP_NTH * u >= nitem) break;                            // (uniform)
+            const int key = e / QPR, qd = e - key * QPR;
+            const float* p = base + (size_t)(k0 + (key < nk ? key : 0)) * 3 * C + D + 4 * qd;
+            kreg[u] = *reinterpret_cast<const f32x4*>(p);
+            vreg[u] = *reinterpret_cast<const f32x4*>(p + D);
         }
-        for (int e = tid; e < 32 * QPR; e += DEEP_NTH) {
-            const int qr = e / QPR, qd = e - qr * QPR;
+        if (tid < 32 * QPR) {
+            const int qr = tid / QPR, qd = tid - qr * QPR;
             const int tok = q0 + qr;
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(base + (size_t)(tok < L ? tok : 0) * 3 * C + 4 * qd);
-            *reinterpret_cast<f32x4*>(Qs + qr * KSTR + 4 * qd) = qv * (a.scale * LOG2E);
+            qregl = *reinterpret_cast<const f32x4*>(base + (size_t)(tok < L ? tok : 0) * 3 * C + 4 * qd);
         }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int e = tid + DEEP_NTH * u;
+            if (DEEP_NTH * u >= nitem) break;
+            if (e < nitem) {
+                const int key = e / QPR, qd = e - key * QPR;
+                const bool in = key < nk;                                // rows past the last key of a tile are zero
+                const f32x4 kv = in ? kreg[u] * a.scale : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(Ks + key * KSTR + 4 * qd) = kv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Vt[(4 * qd + c) * VSTR + key] = in ? vreg[u][c] : 0.f;
+            }
+        }
+        if (tid < 32 * QPR) {
+            const int qr = tid / QPR, qd = tid - qr * QPR;
+            *reinterpret_cast<f32x4*>(Qs + qr * KSTR + 4 * qd) = qregl * (a.scale * LOG2E);
+        }
+    };
+    static_assert(32 * QPR <= DEEP_NTH, "one Q quad per thread");
+    issue(0);
+    for (int hh = 0; hh < HPW; ++hh) {
+        park();
+        if (hh + 1 < HPW) issue(hh + 1);
         if (hh == 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -773,9 +825,9 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         for (int k2 = 0; k2 < kparts; ++k2)
             v += *reinterpret_cast<const f32x4*>(Os + (size_t)(t2 + ntile * k2) * 16 * 20 + (rr & 15) * 20 + ((4 * cq) & 15));
         const int n = cg * NC + 4 * cq;
-        if (hg == 0) {
-            v += *reinterpret_cast<const f32x4*>(a.bias + n);
-            v += slab_sum_rt(a.res.p + ((size_t)b * L + tok) * a.res.C + n, a.res.slab_stride, a.res.ks);
+        if (hg == 0) {                                          // (e == tid: 32 NC / 4 <= 512 quads, one per thread)
+            v += pre_b + pre_r;
+            for (int k2 = 1; k2 < a.res.ks; ++k2) v += *reinterpret_cast<const f32x4*>(a.res.p + (size_t)k2 * a.res.slab_stride + ((size_t)b * L + tok) * a.res.C + n);
         }
         *reinterpret_cast<f32x4*>(a.out + (size_t)hg * a.out_slab_stride + ((size_t)b * L + tok) * C + n) = v;
     }
@@ -872,6 +924,40 @@ bool deep_configure(DeepArgs& a, DeepTile* t) {
     return true;
 }
 
+// Row table of a configured conv (host): per row group [ntaps][ROWS] float offsets into the staged main slice -- row of the source
+// token each (tap, output row) reads, the zero row for padding / rows past the group -- then [ROWS] offsets into the skip slice.
+std::vector<int> deep_rowtab(const DeepArgs& a0, DeepTile t) {
+    DeepArgs a = a0;
+    (void)deep_layout(a, t);
+    const int ROWS = 16 * t.RT, SM = a.CSm + DEEP_PAD, SS = a.CSs + DEEP_PAD;
+    const int r = a.r, tt = a.t, b1 = r * r, L = b1 + 2 * tt * r;
+    const int rs = a.up_main ? r >> 1 : r, b1s = rs * rs;
+    std::vector<int> tab((size_t)a.nrg * (a.ntaps + 1) * ROWS);
+    for (int rg = 0; rg < a.nrg; ++rg) {
+        const int tok0 = (a.nrg == 2 && rg) ? b1 : 0, ntok = a.nrg == 2 ? (rg ? L - b1 : b1) : L;
+        const int stok0 = (a.nrg == 2 && rg) ? b1s : 0;
+        int* tb = tab.data() + (size_t)rg * (a.ntaps + 1) * ROWS;
+        for (int tap = 0; tap < a.ntaps; ++tap)
+            for (int ri = 0; ri < ROWS; ++ri) {
+                int row = -1;
+                if (ri < ntok) {
+                    const int tok = tok0 + ri;
+                    if (a.ntaps == 9) {
+                        const int g = geo_source(r, tt, tok, tap / 3, tap % 3, a.up_main != 0);
+                        row = g < 0 ? -1 : (g & 0x0FFFFFFF) - stok0;
+                    } else if (a.up_main) {
+                        row = (geo_source(r, tt, tok, 1, 1, true) & 0x0FFFFFFF) - stok0;
+                    } else {
+                        row = tok - stok0;
+                    }
+                }
+                tb[tap * ROWS + ri] = row < 0 ? a.src_rows_max * SM : row * SM;
+            }
+        for (int ri = 0; ri < ROWS; ++ri) tb[a.ntaps * ROWS + ri] = ri < ntok ? ri * SS : ROWS * SS;
+    }
+    return tab;
+}
+
 template <int RT, int NT>
 static hipError_t deep_launch_t(const DeepArgs& a, size_t smem, hipStream_t s) {
     hipLaunchKernelGGL((k_deep_conv<RT, NT>), dim3((unsigned)(a.tiles_n * a.nslots)), dim3(DEEP_NTH), smem, s, a);
@@ -886,7 +972,7 @@ hipError_t launch_deep_conv(const DeepArgs& a0, DeepTile t, hipStream_t s) {
     if (a.gn && ((a.gs & 3) || (a.gs & (a.gs - 1)) || a.CSm % a.gs || a.CSm / a.gs > DEEP_MAX_NG)) return hipErrorInvalidValue;
     if (a.N % (16 * t.NT) || (a.N & 3)) return hipErrorInvalidValue;
     if (a.gn && a.whole && a.nrg != 1) return hipErrorInvalidValue;      // statistics over all planes need all planes in one workgroup
-    if (!a.zeros) return hipErrorInvalidValue;
+    if (!a.zeros || !a.rowtab) return hipErrorInvalidValue;
     if (!a.gn) { a.gamma = a.beta = a.zeros; }                           // (the kernel loads these vectors unconditionally)
     if (!a.gn || !a.film) { a.film = a.zeros; a.film_stride = 0; }
     a.tiles_n = a.N / (16 * t.NT);

@@ -265,6 +265,7 @@ struct DeepArgs {
     int film_stride;
     int gs;                  // channels per group
     int gn, whole, act;      // gn: normalise; whole: statistics over all planes (AttentionBlock1D); act: SiLU
+    const int* rowtab;       // device copy of deep_rowtab(): [nrg][(ntaps + 1)][16 RT] LDS offsets (floats)
     const float* zeros;      // >= 2 Cmain zero floats: stands in for absent GroupNorm / FiLM vectors (launch_deep_conv)
     float* out;              // slab 0 of the output [KS][B][Lout][N]
     unsigned out_slab_stride;
@@ -380,6 +381,10 @@ extern int g_attn_b3_min_keys;
 struct DeepTile { int RT, NT; };                 // k_deep_conv<RT, NT>: 16 RT rows x 16 NT columns per workgroup
 size_t deep_weight_floats(const DeepArgs& a, int NT);
 bool deep_tile_for(const DeepArgs& a, DeepTile* t);      // (fills nothing in `a`; false: no instantiation for this row-group size)
+}  // namespace mtv
+#include <vector>
+namespace mtv {
+std::vector<int> deep_rowtab(const DeepArgs& a, DeepTile t);   // host: the row table of a configured conv (upload it, pass it as DeepArgs::rowtab)
 bool deep_configure(DeepArgs& a, DeepTile* t);           // picks row groups / K slices / tile; false: this conv stays on k_conv
 size_t deep_smem_bytes(const DeepArgs& a, DeepTile t);
 hipError_t launch_deep_conv(const DeepArgs& a, DeepTile t, hipStream_t s);

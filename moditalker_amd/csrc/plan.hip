@@ -345,6 +345,17 @@ struct Builder {
         a.out = out.p;
         a.out_slab_stride = out.slab;
         a.W = c->wdeep_for(W, ldw, a, t.NT);
+        {   // row table: one per (geometry, slicing) -- shared by every conv of the context that has the same
+            char key[128];
+            snprintf(key, sizeof key, "deep.rowtab %d %d %d %d %d %d %d %d %d %d", a.r, a.t, a.up_main, a.ntaps, a.nrg, t.RT, a.CSm, a.CSs, a.Cskip ? 1 : 0, a.Lout);
+            if (!c->bufs.count(key)) {
+                const std::vector<int> tab = deep_rowtab(a, t);
+                float* d = c->buf(key, tab.size());
+                if (d && hipMemcpy(d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) d = nullptr;
+                if (!d) { err = "row table upload failed at " + name; return Tens{}; }
+            }
+            a.rowtab = reinterpret_cast<const int*>(c->bufs[key]);
+        }
         if (!a.W || !out.p || !a.zeros) { err = "deep conv allocation failed at " + name; return Tens{}; }
         if (c->accounting) {
             const double m = (double)a.Lout;

@@ -84,6 +84,12 @@ static int run_case(const Case& c) {
     a.tiles_n = c.N / (16 * tl.NT);
     CK(launch_deep_repack(dW, ldw, dWd, a, tl.NT, 0));
     a.W = dWd;
+    {
+        const std::vector<int> tab = deep_rowtab(a, tl);
+        int* dt = dnew<int>(tab.size());
+        CK(hipMemcpy(dt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        a.rowtab = dt;
+    }
     CK(hipMemset(out, 0xFF, (size_t)c.KS * c.B * L * c.N * 4));        // poison: NaN wherever nothing is written
     CK(launch_deep_conv(a, tl, 0));
     CK(hipDeviceSynchronize());
@@ -262,6 +268,7 @@ static void do_chain(int nops, int r, int t, int ks_arg, int nrg_arg) {
     printf("  deep: KS %d nrg %d\n", KS, nrg);
     float* slabs[2] = {dnew<float>((size_t)8 * L * C), dnew<float>((size_t)8 * L * C)};
     float* zeros_d = dnew<float>(2 * C);
+    int* rowtab_d = nullptr;
     CK(hipMemcpy(slabs[0], x.data(), x.size() * 4, hipMemcpyHostToDevice));
     DeepTile tl{};
     for (int o = 0; o < nops; ++o) {
@@ -277,6 +284,12 @@ static void do_chain(int nops, int r, int t, int ks_arg, int nrg_arg) {
         dWd[o] = dnew<float>((size_t)K * N);
         CK(launch_deep_repack(dW[o], ldw, dWd[o], a, tl.NT, 0));
         a.W = dWd[o];
+        if (o == 0) {
+            const std::vector<int> tab = deep_rowtab(a, tl);
+            rowtab_d = dnew<int>(tab.size());
+            CK(hipMemcpy(rowtab_d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        }
+        a.rowtab = rowtab_d;
 #ifdef MTV_DEEP_STAMP
         if (o == nops / 2) a.dbg = dnew<unsigned long long>(64);
 #endif
