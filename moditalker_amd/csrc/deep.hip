@@ -40,7 +40,7 @@ namespace {
 constexpr int DEEP_PAD = 8;          // LDS row stride = slice channels + 8 floats: the 16 lanes of a ds_read_b128 lane group hit
                                      // 16 distinct bank quads (stride/4 = 2 mod 16 over rows i, + q; MI355X_MICROARCH.md LDS table)
 constexpr int DEEP_NTH = 512;
-constexpr int DEEP_MAX_NG = 16;      // GroupNorm groups per channel slice
+constexpr int DEEP_MAX_NG = 32;      // GroupNorm groups per channel slice
 
 __device__ __forceinline__ float deep_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ int deep_usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -144,6 +144,86 @@ __device__ __forceinline__ void stage_slice_ks(const DeepSrc& src, const float* 
         default: stage_slice<8, STATS>(base, src.slab_stride, src.C, nrows, qw_shift, tid, lds, lstride, tok0, b1s, b2s, acc, mid); break;
     }
 }
+
+
+// ---- in-launch completion (DeepFin): shared by k_deep_conv and k_deep_attn --------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long deep_gu64;
+__device__ __forceinline__ void deep_park_quad(float* dst, const f32x4& v) {          // write-through (sc1) 8-byte stores
+    deep_gu64* d = (deep_gu64*)(unsigned long long)dst;
+    __hip_atomic_store(d, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// All slabs of one quad, L1-bypassing loads, all in flight, summed in slab order.
+__device__ __forceinline__ f32x4 deep_gather_quad(const float* slab0, unsigned stride, int ks) {
+    const deep_gu64* s0 = (const deep_gu64*)(unsigned long long)slab0;
+    unsigned long long t0[8], t1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t o = (size_t)(k < ks ? k : 0) * (stride / 2);
+        t0[k] = __hip_atomic_load(s0 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t1[k] = __hip_atomic_load(s0 + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    f32x4 v = {__uint_as_float((unsigned)t0[0]), __uint_as_float((unsigned)(t0[0] >> 32)), __uint_as_float((unsigned)t1[0]), __uint_as_float((unsigned)(t1[0] >> 32))};
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < ks) {
+            v[0] += __uint_as_float((unsigned)t0[k]);
+            v[1] += __uint_as_float((unsigned)(t0[k] >> 32));
+            v[2] += __uint_as_float((unsigned)t1[k]);
+            v[3] += __uint_as_float((unsigned)(t1[k] >> 32));
+        }
+    return v;
+}
+// After every thread of the workgroup has parked its quads: drain, take the tile's ticket; true in the workgroup that arrived last.
+// `scratch`: LDS, [0] = flag, statistics slots from +4 (zeroed here for the last arriver).
+__device__ __forceinline__ bool deep_fin_arrive(const DeepFin& f, int tile, int arrivals, float* scratch, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(scratch);
+    if (tid == 0) {
+        const bool last = __hip_atomic_fetch_add(f.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == arrivals - 1;
+        if (last) __hip_atomic_store(f.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning for the next launch
+        *flag = last ? 1 : 0;
+    }
+    double* st = reinterpret_cast<double*>(scratch + 4);
+    for (int e = tid; e < f.nstat * 96 * 2; e += DEEP_NTH) st[e] = 0.0;
+    __syncthreads();
+    return *flag != 0;
+}
+__device__ __forceinline__ void deep_fin_stat(const DeepFin& f, float* scratch, int tok, int n, const f32x4& v) {
+    double* st = reinterpret_cast<double*>(scratch + 4);
+    const int sg = tok >= f.seg.b2 ? 2 : (tok >= f.seg.b1 ? 1 : 0);
+    for (int t = 0; t < f.nstat; ++t) {
+        const int gs = f.stat[t].gs;
+        if ((gs & 3) == 0) {
+            const int g = (f.stat[t].coff + n) / gs;
+            atomicAdd(&st[((t * 96) + sg * 32 + g) * 2], ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]));
+            atomicAdd(&st[((t * 96) + sg * 32 + g) * 2 + 1], ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int g = (f.stat[t].coff + n + k) / gs;
+                atomicAdd(&st[((t * 96) + sg * 32 + g) * 2], (double)v[k]);
+                atomicAdd(&st[((t * 96) + sg * 32 + g) * 2 + 1], (double)v[k] * v[k]);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void deep_fin_flush(const DeepFin& f, float* scratch, int b, int tid) {
+    if (!f.nstat) return;
+    __syncthreads();
+    const double* st = reinterpret_cast<const double*>(scratch + 4);
+    for (int e = tid; e < f.nstat * 96; e += DEEP_NTH) {
+        const int t = e / 96, r2 = e - t * 96;
+        const double sx = st[e * 2], sy = st[e * 2 + 1];
+        if (sy != 0.0) {
+            double* dst = f.stat[t].sums + (size_t)(blockIdx.x & (STAT_COPIES - 1)) * f.stat_cstride + ((size_t)b * 96 + r2) * 2;
+            atomicAdd(dst, sx);
+            atomicAdd(dst + 1, sy);
+        }
+    }
+}
+constexpr int DEEP_FIN_FLOATS = 4 + 2 * 96 * 2 * 2;      // flag + [2 consumers][96][2] doubles
 
 }  // namespace
 
@@ -479,6 +559,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
     }
     __syncthreads();
     float* const outp = a.out + (size_t)s * a.out_slab_stride;
+    const bool fin = a.fin.out != nullptr;
     for (int e = tid; e < QUADS; e += DEEP_NTH) {
         const int rr = e / QPR, cq = e - rr * QPR;
         if (rr >= rg_ntok) continue;
@@ -487,7 +568,25 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
 #pragma unroll
         for (int w = 1; w < NIMG; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
         if (s == 0) v += (e == tid && pre_ok) ? pre : epi_operands(e);
-        *reinterpret_cast<f32x4*>(outp + ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq) = v;
+        float* dst = outp + ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq;
+        if (fin) deep_park_quad(dst, v);
+        else *reinterpret_cast<f32x4*>(dst) = v;
+    }
+    if (fin) {
+        // ---- in-launch completion: the K slice that arrives last turns the tile's slabs into the plain tensor (+ statistics)
+        float* scratch = smem + a.lds_fin;
+        if (deep_fin_arrive(a.fin, (b * a.nrg + rg) * a.tiles_n + j, a.KS, scratch, tid)) {
+            for (int e = tid; e < QUADS; e += DEEP_NTH) {
+                const int rr = e / QPR, cq = e - rr * QPR;
+                if (rr >= rg_ntok) continue;
+                const int tok = rg_tok0 + rr, n = n0 + 4 * cq;
+                const size_t off = ((size_t)b * a.Lout + tok) * a.N + n;
+                const f32x4 v = deep_gather_quad(a.out + off, a.out_slab_stride, a.KS);
+                *reinterpret_cast<f32x4*>(a.fin.out + off) = v;
+                deep_fin_stat(a.fin, scratch, tok, n, v);
+            }
+            deep_fin_flush(a.fin, scratch, b, tid);
+        }
     }
     DEEP_STAMP(7);
 }
@@ -590,11 +689,13 @@ __device__ __forceinline__ float deep_swap_max32(float x) {
 // rows.  Then D = attention rows x Wp[head group rows][column group] on the same MFMA, K split over the waves, summed in LDS.
 template <int D>
 __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
+    const int tid = threadIdx.x;
+    DEEP_STAMP(0);
     touch_kernargs<(int)sizeof(DeepAttnArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr int KSTR = D + 4, NDT = D / 16, QPR = D / 4;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = deep_usgpr(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int blk = deep_usgpr((int)blockIdx.x);
@@ -621,7 +722,8 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     float* const Att = Qs + 32 * KSTR;                        // [32][AS]: normalised attention rows of the head group
     float* const Wt = Att + 32 * AS;                          // [NC][WS]: proj slice, transposed (k contiguous)
     float* const Os = Wt + NC * WS;                           // [8 waves][16 queries][D + 4]: key-part partials (then proj partials)
-    float* const ml = Os + 8 * 16 * (D + 4);                  // [8 waves][16 queries][2]: (m, l) of the key parts
+    constexpr int OSF = 8 * 16 * (D + 4) > 8 * 16 * 20 + DEEP_FIN_FLOATS ? 8 * 16 * (D + 4) : 8 * 16 * 20 + DEEP_FIN_FLOATS;
+    float* const ml = Os + OSF;                               // [8 waves][16 queries][2]: (m, l) of the key parts
     const int qt = wave & 1, kp = wave >> 1;                  // this wave: query tile, key part
     // ---- proj slice requested first: it depends on nothing (held in registers until the first barrier)
     const int kw = HPW * D, wq = NC >> 2;                     // K rows of the slice, column quads
@@ -687,8 +789,10 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     };
     static_assert(32 * QPR <= DEEP_NTH, "one Q quad per thread");
     issue(0);
+    DEEP_STAMP(1);
     for (int hh = 0; hh < HPW; ++hh) {
         park();
+        if (hh == 0) DEEP_STAMP(2);
         if (hh + 1 < HPW) issue(hh + 1);
         if (hh == 0) {
 #pragma unroll
@@ -702,6 +806,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
             }
         }
         __syncthreads();
+        if (hh == 0) DEEP_STAMP(3);
         // ---- this wave: query tile qt, key tiles kp, kp + 4 (nkt <= 8)
         float qreg[NDT][4];
 #pragma unroll
@@ -771,7 +876,9 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
             for (int o = 0; o < NDT; ++o) *reinterpret_cast<f32x4*>(op + 16 * o) = oacc[o];
             if (g == 0) { ml[(wave * 16 + j) * 2] = m; ml[(wave * 16 + j) * 2 + 1] = lsum; }
         }
+        if (hh == 0) DEEP_STAMP(4);
         __syncthreads();
+        if (hh == 0) DEEP_STAMP(5);
         // ---- merge the four key parts of every query: thread -> (query row, d quad)
         for (int e = tid; e < 32 * QPR; e += DEEP_NTH) {
             const int qr = e / QPR, dq = e - qr * QPR;
@@ -797,6 +904,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         }
         __syncthreads();
     }
+    DEEP_STAMP(6);
     // ---- proj: [32 rows][NC cols] = Att [32][kw] x Wt^T; wave -> (tile, K part)
     const int nct = NC >> 4, ntile = 2 * nct, kparts = 8 / ntile;       // (ntile 2 or 4)
     const int tile = wave % ntile, kpart = wave / ntile;
@@ -815,6 +923,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         for (int rr = 0; rr < 4; ++rr) pp[rr * 20] = pacc[rr];
     }
     __syncthreads();
+    DEEP_STAMP(7);
     // epilogue: thread -> (row, column quad); K parts summed in order; head group 0 adds bias + residual
     for (int e = tid; e < 32 * (NC >> 2); e += DEEP_NTH) {
         const int rr = e / (NC >> 2), cq = e - rr * (NC >> 2);
@@ -829,8 +938,27 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
             v += pre_b + pre_r;
             for (int k2 = 1; k2 < a.res.ks; ++k2) v += *reinterpret_cast<const f32x4*>(a.res.p + (size_t)k2 * a.res.slab_stride + ((size_t)b * L + tok) * a.res.C + n);
         }
-        *reinterpret_cast<f32x4*>(a.out + (size_t)hg * a.out_slab_stride + ((size_t)b * L + tok) * C + n) = v;
+        float* dst = a.out + (size_t)hg * a.out_slab_stride + ((size_t)b * L + tok) * C + n;
+        if (a.fin.out) deep_park_quad(dst, v);
+        else *reinterpret_cast<f32x4*>(dst) = v;
     }
+    if (a.fin.out) {
+        // ---- in-launch completion over the head groups (the K slices of the projection)
+        float* scratch = Os + 8 * 16 * 20;                       // past the proj partials
+        if (deep_fin_arrive(a.fin, (b * a.nqg + qg) * a.ncg + cg, a.nhg, scratch, tid)) {
+            for (int e = tid; e < 32 * (NC >> 2); e += DEEP_NTH) {
+                const int rr = e / (NC >> 2), cq = e - rr * (NC >> 2);
+                const int tok = q0 + rr, n = cg * NC + 4 * cq;
+                if (tok >= L) continue;
+                const size_t off = ((size_t)b * L + tok) * C + n;
+                const f32x4 v = deep_gather_quad(a.out + off, a.out_slab_stride, a.nhg);
+                *reinterpret_cast<f32x4*>(a.fin.out + off) = v;
+                deep_fin_stat(a.fin, scratch, tok, n, v);
+            }
+            deep_fin_flush(a.fin, scratch, b, tid);
+        }
+    }
+    DEEP_STAMP(9);
 }
 
 // =====================================================================================
@@ -888,25 +1016,27 @@ static size_t deep_layout(DeepArgs& a, DeepTile t) {
     a.lds_red = 0;                                                     // the reduction scratch reuses the staged slices
     const int LDR = 16 * t.NT + 4;
     const int red = (8 * ROWS * LDR * 4 <= 96 * 1024 ? 8 : 4) * ROWS * LDR;
-    return (size_t)(off > red ? off : red) * 4;
+    a.lds_fin = ((off > red ? off : red) + 3) & ~3;                     // completion scratch: past everything the epilogue still reads
+    return (size_t)(a.lds_fin + DEEP_FIN_FLOATS) * 4;
 }
 
 // Slicing of one conv of the deep levels: row groups, column tile, K slices.  `a` arrives with sources, channel counts, geometry and
 // GroupNorm flags set; on success nrg / KS / CSm / CSs / tiles_n are filled in.  K slices: the most that keep the grid at <= 256
 // workgroups (one per CU: every CU streams its share of the weights), within what the kernel supports -- power-of-two slices of
 // 16 ... 256 channels that hold whole GroupNorm groups and do not straddle the parts of a channel concatenation.
-bool deep_configure(DeepArgs& a, DeepTile* t) {
+bool deep_configure(DeepArgs& a, DeepTile* t, int max_ks) {
     if (a.B < 1 || a.Lout < 1 || a.Lout > 128 || (a.N & 15) || (a.Cmain & 15) || (a.Cskip & 15)) return false;
     if (a.ntaps != 9 && a.ntaps != 1) return false;
     a.nrg = (a.Lout > 64 && !(a.gn && a.whole)) ? 2 : 1;
     if (!deep_tile_for(a, t)) return false;
+    if (max_ks == 1) t->NT = 1;                        // un-sliced K (plain output): column tiles are the only parallelism
     a.tiles_n = a.N / (16 * t->NT);
     const int C0m = a.main[1].p ? a.main[0].C : 0, C0s = a.skip[1].p ? a.skip[0].C : 0;
     int best = 0;
-    for (int KS = 1; KS <= 8; KS *= 2) {
+    for (int KS = 1; KS <= max_ks; KS *= 2) {
         if (a.Cmain % KS) continue;
         const int CSm = a.Cmain / KS, CSs = a.Cskip / KS;
-        if (CSm < 16 || CSm > 256 || (CSm & (CSm - 1)) || (C0m && C0m % CSm)) continue;
+        if (CSm < 16 || CSm > 512 || (CSm & (CSm - 1)) || (C0m && C0m % CSm)) continue;
         if (a.gn && ((a.gs & 3) || (a.gs & (a.gs - 1)) || CSm % a.gs || CSm / a.gs > DEEP_MAX_NG)) continue;
         if (a.Cskip && (a.Cskip % KS || CSs < 16 || CSs > 256 || (CSs & (CSs - 1)) || (C0s && C0s % CSs))) continue;
         DeepArgs probe = a;
@@ -967,7 +1097,7 @@ static hipError_t deep_launch_t(const DeepArgs& a, size_t smem, hipStream_t s) {
 hipError_t launch_deep_conv(const DeepArgs& a0, DeepTile t, hipStream_t s) {
     DeepArgs a = a0;
     if (a.KS < 1 || (a.KS & (a.KS - 1)) || a.KS > 8 || (a.nrg != 1 && a.nrg != 2)) return hipErrorInvalidValue;
-    if (a.CSm < 16 || (a.CSm & (a.CSm - 1)) || a.CSm > 256 || a.CSm * a.KS != a.Cmain) return hipErrorInvalidValue;
+    if (a.CSm < 16 || (a.CSm & (a.CSm - 1)) || a.CSm > 512 || a.CSm * a.KS != a.Cmain) return hipErrorInvalidValue;
     if (a.Cskip && (a.CSs * a.KS != a.Cskip || (a.CSs & (a.CSs - 1)) || a.CSs < 16 || a.CSs > 256)) return hipErrorInvalidValue;
     if (a.gn && ((a.gs & 3) || (a.gs & (a.gs - 1)) || a.CSm % a.gs || a.CSm / a.gs > DEEP_MAX_NG)) return hipErrorInvalidValue;
     if (a.N % (16 * t.NT) || (a.N & 3)) return hipErrorInvalidValue;
@@ -1030,7 +1160,8 @@ hipError_t launch_deep_repack(const float* W, int ldw, float* dst, const DeepArg
 
 static size_t deep_attn_smem(const DeepAttnArgs& a, int D) {
     const int KSTR = D + 4, VSTR = a.kcap + 4, AS = a.HPW * D + 8, WS = a.HPW * D + 4;
-    return (size_t)(a.kcap * KSTR + D * VSTR + 32 * KSTR + 32 * AS + a.NC * WS + 8 * 16 * (D + 4) + 8 * 16 * 2) * 4;
+    const int os = 8 * 16 * (D + 4) > 8 * 16 * 20 + DEEP_FIN_FLOATS ? 8 * 16 * (D + 4) : 8 * 16 * 20 + DEEP_FIN_FLOATS;   // key-part partials | proj partials + completion scratch
+    return (size_t)(a.kcap * KSTR + D * VSTR + 32 * KSTR + 32 * AS + a.NC * WS + os + 8 * 16 * 2) * 4;
 }
 
 bool deep_attn_configure(DeepAttnArgs& a) {

@@ -244,6 +244,19 @@ struct DeepSrc {
     int C;                   // channels = row stride
 };
 
+// Optional in-launch completion of a deep tensor (a consumer outside the deep region -- k_conv, k_pool_down, k_attention, the
+// attention blocks' qkv -- wants ONE plain tensor and, for GroupNorm, its statistics): every K slice parks its partial tile with
+// write-through 8-byte stores and takes a ticket; the slice that draws the last one re-reads all slabs (slab order), writes the
+// plain tile and adds the statistics -- conv.hip's split-K completion (cdna_hip_programming.md G16: 8-byte agent atomics both sides).
+struct DeepFin {
+    float* out;              // plain [B][L][N] (nullptr: slabs only)
+    int* tickets;            // one per output tile (zero between launches: the last slice resets its own)
+    StatOut stat[2];
+    int nstat;
+    unsigned stat_cstride;
+    SegInfo seg;             // plane boundaries of the output level
+};
+
 struct DeepArgs {
     DeepSrc main[2];         // tapped source, <= 2 parts concatenated along channels (main[1].p == nullptr: one part)
     DeepSrc skip[2];         // parts of the fused 1x1 skip conv (raw, rows = output tokens); skip[0].p == nullptr: none
@@ -282,6 +295,8 @@ struct DeepArgs {
     int src_rows_max;        // rows of the staged main slice (largest row group) -- its zero row follows
     double inv_n[4];         // 1 / (tokens x gs) of source plane 0, 1, 2 and of all planes together
     unsigned long long* dbg; // -DMTV_DEEP_STAMP builds (tools/ubench/deep_bench): phase timestamps of two sampled workgroups, else unused
+    DeepFin fin;
+    int lds_fin;             // LDS offset (floats) of the completion scratch (flag + statistics slots)
 };
 
 // slabs -> one plain tensor (+ GroupNorm statistics into the site tables of legacy consumers): the exits of the deep region
@@ -315,6 +330,8 @@ struct DeepAttnArgs {
     int kcap;                // key capacity of the LDS tiles: 16 ceil(L / 16)
     float inv_nslots;
     int nslots;              // B * nqg * nhg
+    unsigned long long* dbg; // -DMTV_DEEP_STAMP builds: phase timestamps, else unused
+    DeepFin fin;
 };
 
 struct LinearArgs {
@@ -385,7 +402,7 @@ bool deep_tile_for(const DeepArgs& a, DeepTile* t);      // (fills nothing in `a
 #include <vector>
 namespace mtv {
 std::vector<int> deep_rowtab(const DeepArgs& a, DeepTile t);   // host: the row table of a configured conv (upload it, pass it as DeepArgs::rowtab)
-bool deep_configure(DeepArgs& a, DeepTile* t);           // picks row groups / K slices / tile; false: this conv stays on k_conv
+bool deep_configure(DeepArgs& a, DeepTile* t, int max_ks = 8);   // picks row groups / K slices (<= max_ks) / tile; false: this conv stays on k_conv
 size_t deep_smem_bytes(const DeepArgs& a, DeepTile t);
 hipError_t launch_deep_conv(const DeepArgs& a, DeepTile t, hipStream_t s);
 hipError_t launch_deep_repack(const float* W, int ldw, float* dst, const DeepArgs& a, int NT, hipStream_t s);   // legacy [krow][ldw] -> deep layout

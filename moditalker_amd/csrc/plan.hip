@@ -213,7 +213,9 @@ struct Builder {
     int film_stride;     // floats between batch elements of film_out (0 in a sampler step)
     std::string err;
     std::map<const float*, std::shared_ptr<ConvOp>> producer;   // tensor -> the conv that writes it
-    std::map<const float*, std::shared_ptr<FinOp>> fin_producer;   // plain copy of a deep tensor -> the finalize pass that writes it
+    std::map<const float*, StatSink> fin_producer;                 // plain copy of a deep tensor -> where its statistics targets go
+    std::map<const float*, std::shared_ptr<DeepOp>> deep_producer; // deep tensor (slab 0) -> the conv that writes it
+    std::map<const float*, std::shared_ptr<DeepAttnOp>> attn_producer;   // ... or the fused attention block
     std::map<const float*, Tens> fin_cache;                        // deep tensor (slab 0) -> its plain copy, made once
 
     Builder(mtv_ctx* ctx, Plan* p, int batch, int md)
@@ -376,6 +378,7 @@ struct Builder {
         const double flops = 2.0 * B * a.Lout * a.N * K;
         const double bytes = 4.0 * (K * a.N + a.N) + 4.0 * B * ((double)a.Lsrc * a.Cmain + (double)a.Lout * a.Cskip + (double)a.Lout * a.N + (a.res.p ? (double)a.Lout * a.N : 0.0));
         push(std::string(a.ntaps == 9 ? "conv3:" : "conv1:") + name + deep_tag(a, t), [op](hipStream_t s) { return launch_deep_conv(op->a, op->t, s); }, flops, bytes);
+        if (out.ks > 1) deep_producer[out.p] = op;
         return out;
     }
     // a plain copy of a deep tensor for a consumer outside the deep region (k_conv, k_pool_down): made once per tensor
@@ -387,6 +390,32 @@ struct Builder {
         o.lvl = x.lvl;
         o.C = x.C;
         o.p = c->act(name + ".fin", x.lvl, x.C);
+        // Default: a separate k_deep_finalize pass (4.6 us + a kernel boundary).  MTV_DEEP_INLAUNCH=1: completion inside the
+        // producing kernel instead (its last-arriving K slice re-reads the slabs and writes the plain tensor + statistics; consumers
+        // emitted so far keep reading the slabs) -- parity-green, and measured no faster: the store -> drain -> ticket -> re-read
+        // chain adds 4-4.5 us to the producing launch (conv3 at 32 tokens 8.3 -> 10.1 us, at 128 tokens 15.1 -> 17.1, the
+        // attention block 10.6 -> 14.8), the same three dependent round trips as k_conv's split-K completion.
+        static const bool fin_launch = []() { const char* e = getenv("MTV_DEEP_INLAUNCH"); return !(e && atoi(e) != 0); }();
+        DeepFin* fn = nullptr;
+        std::shared_ptr<void> owner;
+        long ntile = 0;
+        if (!fin_launch) {
+            auto dp = deep_producer.find(x.p);
+            auto ap = attn_producer.find(x.p);
+            if (dp != deep_producer.end()) { fn = &dp->second->a.fin; owner = dp->second; ntile = (long)B * dp->second->a.nrg * dp->second->a.tiles_n; }
+            else if (ap != attn_producer.end()) { fn = &ap->second->a.fin; owner = ap->second; ntile = (long)B * ap->second->a.nqg * ap->second->a.ncg; }
+        }
+        if (fn) {
+            fn->out = o.p;
+            fn->tickets = reinterpret_cast<int*>(c->buf("deep.tickets." + name + ".B" + std::to_string(B), (size_t)ntile));
+            fn->nstat = 0;
+            fn->stat_cstride = (unsigned)c->stats_copy_doubles;
+            fn->seg = c->lv[x.lvl].seg();
+            if (!fn->tickets) { err = "ticket allocation failed at " + name; return Tens{}; }
+            fin_producer[o.p] = StatSink{fn->stat, &fn->nstat, owner};
+            fin_cache[x.p] = o;
+            return o;
+        }
         auto op = std::make_shared<FinOp>();
         op->a.src = dsrc(x);
         op->a.out = o.p;
@@ -394,7 +423,7 @@ struct Builder {
         op->a.L = c->lv[x.lvl].L;
         op->a.seg = c->lv[x.lvl].seg();
         op->a.stat_cstride = (unsigned)c->stats_copy_doubles;
-        fin_producer[o.p] = op;
+        fin_producer[o.p] = StatSink{op->a.stat, &op->a.nstat, op};
         fin_cache[x.p] = o;
         char tag[64];
         snprintf(tag, sizeof tag, "[%dx%d ks%d]", op->a.L, x.C, x.ks);
@@ -411,7 +440,7 @@ struct Builder {
         for (auto& p : parts) {
             auto it = producer.find(p.p);
             auto fi = fin_producer.find(p.p);
-            if (fi != fin_producer.end()) { if (fi->second->a.nstat >= 2) fused = false; }
+            if (fi != fin_producer.end()) { if (*fi->second.nstat >= 2) fused = false; }
             else if (it == producer.end() || it->second->a.nstat >= 2 || it->second->a.out_cm) fused = false;
         }
         if (fused) {
@@ -419,8 +448,7 @@ struct Builder {
             for (auto& p : parts) {
                 auto fi = fin_producer.find(p.p);
                 if (fi != fin_producer.end()) {
-                    DeepFinArgs& fa = fi->second->a;
-                    fa.stat[fa.nstat++] = StatOut{site, ct / 32, coff, 1.0f / (float)(ct / 32)};
+                    fi->second.stat[(*fi->second.nstat)++] = StatOut{site, ct / 32, coff, 1.0f / (float)(ct / 32)};
                 } else {
                     ConvArgs& pa = producer[p.p]->a;
                     pa.stat[pa.nstat++] = StatOut{site, ct / 32, coff, 1.0f / (float)(ct / 32)};
@@ -736,9 +764,11 @@ struct Builder {
             }
             char tag[96];
             snprintf(tag, sizeof tag, "[L%d d%d %s +proj h%d,c%d]", L.L, d, whole ? "1d" : "2d", da.HPW, da.NC);
-            const DeepAttnArgs dac = da;
-            push("attn:" + nm + tag, [dac](hipStream_t s) { return launch_deep_attn(dac, s); }, aflops + 2.0 * B * (double)L.L * C * C,
+            auto aop = std::make_shared<DeepAttnOp>();
+            aop->a = da;
+            push("attn:" + nm + tag, [aop](hipStream_t s) { return launch_deep_attn(aop->a, s); }, aflops + 2.0 * B * (double)L.L * C * C,
                  4.0 * B * L.L * (3.0 * C + 2.0 * C) + 4.0 * (double)C * C);
+            if (out.ks > 1) attn_producer[out.p] = aop;
             return out;
         };
         if (deep_on(lvl) && deep_qkv_env) {
@@ -766,6 +796,23 @@ struct Builder {
             }
         }
         const Tens x = materialize(x0, nm + ".in");       // k_conv reads a plain tensor and the statistics its producer left
+        if (fused) {
+            // qkv from the plain input with the whole K per workgroup (no slices: the output is one plain tensor, which is what
+            // the attention needs), GroupNorm statistics computed in the kernel -- where all channels of a row group fit in LDS
+            // (32 tokens; 128 tokens per plane group, not with whole-L statistics)
+            // (off by default: measured 9.5 us against k_conv's 7.9 at 32 tokens -- 96 workgroups, each staging the whole input)
+            static const bool ks1_env = []() { const char* e = getenv("MTV_DEEP_QKV1"); return e && atoi(e) != 0; }();
+            DeepArgs dq = deep_args(lvl, 1, 3 * C, bq);
+            dq.Cmain = C;
+            dq.main[0] = dsrc(x);
+            dq.gn = 1; dq.whole = whole ? 1 : 0; dq.act = 0; dq.gs = C / 32; dq.gamma = gw; dq.beta = gb;
+            DeepTile tq{};
+            if (ks1_env && deep_configure(dq, &tq, 1)) {
+                const Tens qkvd = emit_deep(dq, tq, Wq, ldq, nm + ".qkv", lvl);
+                if (!err.empty()) return Tens{};
+                return emit_fused(qkvd.p, x);
+            }
+        }
         double* site = c->new_site();
         add_stats({x}, lvl, site);
         float* qkv = c->act(nm + ".qkv", lvl, 3 * C);

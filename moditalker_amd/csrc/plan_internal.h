@@ -98,6 +98,14 @@ struct DeepOp {                 // one K-sliced conv of the deep levels (deep.hi
 struct FinOp {                  // slabs -> plain tensor (+ statistics for legacy consumers)
     DeepFinArgs a;
 };
+struct DeepAttnOp {             // attention core + proj_out of a deep level (k_deep_attn)
+    DeepAttnArgs a;
+};
+struct StatSink {               // where add_stats() attaches the statistics targets of a tensor that left the deep region:
+    StatOut* stat;              // the stat[2] / nstat of whichever op writes the plain copy (k_deep_finalize, or the in-launch
+    int* nstat;                 // completion of the producing k_deep_conv / k_deep_attn); the op is kept alive by `owner`
+    std::shared_ptr<void> owner;
+};
 
 // A plan is built per (batch size, mode).  FORWARD: one UNetModel.forward for arbitrary per-clip timesteps
 // (time-embedding chain + input packing + UNet -> eps).  STEP0 / STEP1: one denoising step of the sampler, UNet

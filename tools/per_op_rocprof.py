@@ -40,7 +40,7 @@ for us, k in tab:
     if f in ("conv3", "conv1"):
         f += " M" + re.search(r"\[(\d+)x", k).group(1)
     if f == "attn":
-        mm = re.search(r"\[L(\d+) d(\d+) (\w+)\]", k)
+        mm = re.search(r"\[L(\d+) d(\d+) (\w+)", k)
         f += f" L{mm.group(1)} {mm.group(3)}"
     fam[f][0] += 1
     fam[f][1] += us

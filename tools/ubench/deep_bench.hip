@@ -348,6 +348,113 @@ static void do_chain(int nops, int r, int t, int ks_arg, int nrg_arg) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- k_deep_attn
+static int run_attn(int r, int t, int C, int H, int whole, int res_ks, bool timing) {
+    const int b1 = r * r, b2 = b1 + t * r, L = b2 + t * r, d = C / H, ldw = (C + 63) / 64 * 64, B = 1;
+    std::vector<float> qkv((size_t)B * L * 3 * C), W((size_t)C * ldw), bias(C), xr;
+    for (auto& v : qkv) v = frand();
+    const float wsc = 1.0f / sqrtf((float)C);
+    for (auto& v : W) v = frand() * wsc;
+    for (auto& v : bias) v = frand() * 0.1f;
+    DeepAttnArgs a{};
+    a.qkv = dup(qkv); a.B = B; a.L = L; a.C = C; a.H = H; a.r = r; a.t = t; a.whole = whole;
+    a.scale = 1.0f / sqrtf(sqrtf((float)d));
+    a.Wp = dup(W); a.ldw = ldw; a.bias = dup(bias);
+    a.res = make_src(B, L, C, res_ks, xr);
+    if (!deep_attn_configure(a)) { printf("attn L%d d%d: not configurable\n", L, d); return 1; }
+    float* out = dnew<float>((size_t)8 * B * L * C);
+    a.out = out; a.out_slab_stride = (unsigned)((size_t)B * L * C);
+#ifdef MTV_DEEP_STAMP
+    a.dbg = dnew<unsigned long long>(64);
+#endif
+    CK(hipMemset(out, 0xFF, (size_t)8 * B * L * C * 4));
+    CK(launch_deep_attn(a, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<float> got((size_t)a.nhg * B * L * C);
+    CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+    // CPU reference (double): softmax(q k^T d^-1/2) v per head over the keys the query may see, then proj + bias + residual
+    std::vector<double> att((size_t)L * C), ref((size_t)L * C);
+    for (int h = 0; h < H; ++h)
+        for (int q = 0; q < L; ++q) {
+            const int qp = q >= b2 ? 2 : (q >= b1 ? 1 : 0);
+            std::vector<double> sc(L, -1e300);
+            double mx = -1e300;
+            for (int k = 0; k < L; ++k) {
+                const int kp = k >= b2 ? 2 : (k >= b1 ? 1 : 0);
+                if (!whole && kp != qp) continue;
+                double s = 0;
+                for (int e = 0; e < d; ++e) s += (double)qkv[(size_t)q * 3 * C + h * 3 * d + e] * qkv[(size_t)k * 3 * C + h * 3 * d + d + e];
+                sc[k] = s / sqrt((double)d);
+                mx = std::max(mx, sc[k]);
+            }
+            double den = 0;
+            for (int k = 0; k < L; ++k) if (sc[k] > -1e299) { sc[k] = exp(sc[k] - mx); den += sc[k]; } else sc[k] = 0;
+            for (int e = 0; e < d; ++e) {
+                double o = 0;
+                for (int k = 0; k < L; ++k) o += sc[k] * qkv[(size_t)k * 3 * C + h * 3 * d + 2 * d + e];
+                att[(size_t)q * C + h * d + e] = o / den;
+            }
+        }
+    for (int q = 0; q < L; ++q)
+        for (int n = 0; n < C; ++n) {
+            double o = bias[n] + xr[(size_t)q * C + n];
+            for (int k = 0; k < C; ++k) o += att[(size_t)q * C + k] * W[(size_t)k * ldw + n];
+            ref[(size_t)q * C + n] = o;
+        }
+    double worst = 0, sc2 = 0;
+    bool nan = false;
+    for (size_t e = 0; e < ref.size(); ++e) {
+        double s2 = 0;
+        for (int k = 0; k < a.nhg; ++k) { const float v = got[(size_t)k * ref.size() + e]; if (v != v) nan = true; s2 += v; }
+        worst = std::max(worst, fabs(s2 - ref[e]));
+        sc2 = std::max(sc2, fabs(ref[e]));
+    }
+    const bool ok = !nan && worst <= 1e-4 * std::max(1.0, sc2);
+    printf("attn+proj L%-3d C%-3d d%-2d %s res_ks%d  HPW%d NC%d -> %d slabs, %d WGs  max|err| %.3e (|ref| <= %.2f)%s  %s\n", L, C, d, whole ? "1d" : "2d", res_ks, a.HPW, a.NC,
+           a.nhg, a.ncg * a.B * a.nqg * a.nhg, worst, sc2, nan ? " NaN" : "", ok ? "PASS" : "FAIL");
+    if (timing) {
+        hipStream_t s; CK(hipStreamCreate(&s));
+        hipGraph_t gr; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 20; ++i) CK(launch_deep_attn(a, s));
+        CK(hipStreamEndCapture(s, &gr));
+        CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < 20; ++i) CK(hipGraphLaunch(ge, s));
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("    %.2f us per launch (graph of 20 back-to-back launches, boundary included)\n", ms * 1e3 / 400);
+#ifdef MTV_DEEP_STAMP
+        unsigned long long h[64];
+        CK(hipMemcpy(h, a.dbg, sizeof h, hipMemcpyDeviceToHost));
+        for (int blk = 0; blk < 2; ++blk) {
+            printf("    stamps wg %s (cycles since entry):", blk ? "mid" : "0");
+            for (int k = 1; k < 12; ++k) if (h[blk * 32 + k]) printf(" [%d] %lld", k, (long long)(h[blk * 32 + k] - h[blk * 32]));
+            printf("\n");
+        }
+#endif
+    }
+    return ok ? 0 : 1;
+}
+static int do_attn(bool timing) {
+    int bad = 0;
+    bad += run_attn(4, 2, 512, 8, 1, 1, timing);
+    bad += run_attn(4, 2, 512, 8, 0, 4, timing);
+    bad += run_attn(8, 4, 512, 8, 1, 1, timing);
+    bad += run_attn(8, 4, 512, 8, 0, 8, timing);
+    bad += run_attn(8, 4, 128, 8, 1, 2, false);       // the test-size model: d = 16
+    bad += run_attn(8, 4, 128, 8, 0, 1, false);
+    bad += run_attn(8, 4, 256, 8, 1, 1, false);       // d = 32
+    bad += run_attn(6, 3, 256, 8, 0, 1, false);       // ragged planes 36 | 18 | 18
+    bad += run_attn(3, 1, 128, 2, 0, 1, false);       // 15 tokens, d = 64
+    printf("%s (%d failing)\n", bad ? "ATTN CHECK FAILED" : "ATTN CHECK OK", bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && !strcmp(argv[1], "check")) { CK(deep_init_attrs()); return do_check(); }
     if (argc >= 2 && !strcmp(argv[1], "chain")) {
@@ -356,6 +463,7 @@ int main(int argc, char** argv) {
         do_chain(nops, r, t, argc >= 6 ? atoi(argv[5]) : 0, argc >= 7 ? atoi(argv[6]) : 0);
         return 0;
     }
-    printf("usage: deep_bench check | chain [nops] [r t]\n");
+    if (argc >= 2 && !strcmp(argv[1], "attn")) { CK(deep_init_attrs()); return do_attn(argc >= 3); }
+    printf("usage: deep_bench check | chain [nops] [r t] | attn [time]\n");
     return 1;
 }
