@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--steps", type=int, default=250)
     ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=8, help="timed oracle steps for the cpu_baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed oracle steps for the cpu_baseline leg")
     ap.add_argument("--profile-iters", type=int, default=5)
     ap.add_argument("--batched-clips", type=int, default=8,
                     help="extra, informational: steps/s with this many clips batched on ONE GPU (0 = skip); never `value`")
@@ -151,11 +151,16 @@ def main():
         torch.cuda.synchronize(dev)
 
     xw = x.clone()
+    gpu_sections = {}                             # wall time of the sections in which the GPU works (host-synchronised on both sides)
+    t_sec = time.perf_counter()
     run(max(args.ramp_steps, 1), xw)              # set-up: builds the plan, loads/tunes tiles, captures the graphs, ramps clocks
     torch.cuda.synchronize(dev)
+    gpu_sections["setup_and_ramp"] = time.perf_counter() - t_sec
+    t_sec = time.perf_counter()
     if W > 0:
         run(W, xw)                                # the W untimed warm-up steps of the contract
     barrier()
+    gpu_sections["warmup"] = time.perf_counter() - t_sec
     xt = x.clone()
     t0 = time.perf_counter()
     run(K, xt)
@@ -185,16 +190,21 @@ def main():
                          note="per_rank_ms_per_step = each rank's own K steps (host-synchronised before the gather); "
                               "`value` uses the max over ranks of the whole region, gather and closing barrier included")
     dt = float(tmax.item())
+    gpu_sections["timed_steps"] = dt
     assert torch.isfinite(xt).all()
 
     result = None
     if rank == 0:
         work = um.work(dev)
         # ---- roofline of the dominant kernel family, measured live with hipEvents around every launch
+        t_sec = time.perf_counter()
         prof = um.profile_forward(1, args.profile_iters, dev, step=True)   # the launches of one SAMPLER step
+        gpu_sections["per_launch_profile"] = time.perf_counter() - t_sec
         fam = {}
         for p in prof:
             key = p["name"].split(":")[0]
+            if key == "attn" and "+proj" in p["name"]:
+                key = "attnproj"                   # k_deep_attn: attention core + proj_out of a deep level in one launch (csrc/deep.hip)
             f = fam.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             f["ms"] += p["ms"]
             f["flops"] += p["flops"]
@@ -205,6 +215,11 @@ def main():
                     bytes=fam.get("conv3", {}).get("bytes", 0) + fam.get("conv1", {}).get("bytes", 0),
                     launches=fam.get("conv3", {}).get("launches", 0) + fam.get("conv1", {}).get("launches", 0))
         attn = fam.get("attn", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        # (the conv family = k_conv + the K-sliced k_deep_conv of the <= 128-token levels: op names "conv3:" / "conv1:" either way)
+        deep = dict(ms=0.0, flops=0.0, bytes=0.0, launches=0)
+        for p in prof:
+            if p["name"].startswith("conv") and " d" in p["name"].split("[")[-1]:
+                deep["ms"] += p["ms"]; deep["flops"] += p["flops"]; deep["bytes"] += p["bytes"]; deep["launches"] += 1
         step_ms_events = sum(f["ms"] for f in fam.values())
         # An event record between two launches costs a few us that rocprofv3 does not see.  Calibrate it
         # from this run: (sum of the event-bracketed launches) - (timed step) spread over the launches, and
@@ -212,7 +227,7 @@ def main():
         # (profiles/r01_step_summary.txt: the two agree to ~1 %).  The raw figures are kept beside it.
         n_prof = max(1, len(prof))
         ev_ms = max(0.0, (step_ms_events - 1e3 * dt / K) / n_prof)
-        for f in list(fam.values()) + [conv, attn]:
+        for f in list(fam.values()) + [conv, attn, deep]:
             if "ms_raw" in f:                     # `attn` is fam["attn"] itself
                 continue
             f["ms_raw"] = f["ms"]
@@ -233,7 +248,7 @@ def main():
             hbm_counter_GBs = round((2.0 * ec["fetch_raw_MB_per_step"] + ec["write_raw_MB_per_step"]) * 1e6 / (conv["ms"] * 1e-3) / 1e9, 1)
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
-        roofline = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TF,
+        roofline = dict(bound="mfma", kernel=dom_name if dom_name != "k_conv" else "k_conv + k_deep_conv (every conv launch)", achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TF,
                         unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TF, 4), traffic=traffic, traffic_unit="bytes/launch",
                         traffic_source=traffic_src,
                         launches_per_step=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / max(1, dom["launches"]), 3),
@@ -262,6 +277,11 @@ def main():
         families = {k: dict(ms_per_step=round(v["ms"], 4), launches=v["launches"],
                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] else None)
                     for k, v in fam.items()}
+        if deep["launches"]:
+            # the weight-streaming convs of the deep levels on their own: algorithmic bytes (weights once + activations) per second
+            families["conv_deep_levels(k_deep_conv)"] = dict(ms_per_step=round(deep["ms"], 4), launches=deep["launches"],
+                                                             tflops=round(deep["flops"] / (deep["ms"] * 1e-3) / 1e12, 2),
+                                                             algorithmic_GBs=round(deep["bytes"] / (deep["ms"] * 1e-3) / 1e9, 1))
         # ---- CPU baseline: the oracle (PyTorch CPU restatement of the reference) on this box's cores
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -294,40 +314,57 @@ def main():
                         break
                 return img, done
 
-            # BASELINE.md section 3's rule: torch.set_num_threads(<physical cores of the box>) -- that is `value`.
-            # This B=1 workload cannot use that many threads (oneDNN/bmm at 2048 tokens scale to ~8-16), so the
-            # best of a small probe is reported beside it as `best_threads` (never instead of it).
-            torch.set_num_threads(ncores)
-            cpu_steps(1, xc)                      # warm-up (allocator, oneDNN primitives)
-            tc = time.perf_counter()
-            _, cpu_done = cpu_steps(args.cpu_steps, xc, budget_s=30.0)
-            tc = time.perf_counter() - tc
-            cand = sorted({t for t in (8, 16, 32) if t < ncores})
-            best_t, best_dt = None, 1e30
-            for tcount in cand:
-                torch.set_num_threads(tcount)
-                cpu_steps(1, xc)
-                t1 = time.perf_counter()
-                cpu_steps(2, xc)
-                d1 = (time.perf_counter() - t1) / 2
-                if d1 < best_dt:
-                    best_t, best_dt = tcount, d1
+            # Two figures, both labelled.  `value`: >= 10 timed steps after 2 warm-up steps (BASELINE.md section 3's run length) at the
+            # thread count this B=1 workload actually scales to (oneDNN / bmm at 2048 tokens stop scaling at 8-32 threads; the best
+            # of a 1-step probe) -- `cores` is that count.  `physical_cores_rule`: BASELINE.md section 3's thread rule,
+            # torch.set_num_threads(<physical cores>), under a time budget (on some boxes 128 oracle threads crawl at 30-50 s per
+            # step: the default run must still finish within minutes) -- reported beside it, never instead of it.
             model = ""
             try:
                 model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
             except (OSError, IndexError):
                 pass
-            cpu = dict(value=round(cpu_done / tc, 4), unit="denoise-steps/s", cores=ncores, kind="port",
-                       sample=f"first {cpu_done} of the 250 DDIM steps of the same clip after 1 warm-up step (up to {args.cpu_steps}, 30 s budget), "
-                              f"torch.set_num_threads({ncores}) = physical cores (BASELINE.md section 3; {os.cpu_count()} logical CPUs, "
-                              f"{model}), oracle/ref_unet.py op-for-op PyTorch {torch.__version__} CPU restatement, fp32",
-                       best_threads=dict(threads=best_t, value=round(1.0 / best_dt, 4),
-                                         sample=f"2 steps each at {cand} threads") if best_t else None)
+            cand = sorted({t for t in (8, 16, 32) if t <= ncores}) or [ncores]
+            probe = {}
+            for tcount in cand:
+                torch.set_num_threads(tcount)
+                cpu_steps(1, xc)                  # (allocator, oneDNN primitives)
+                t1 = time.perf_counter()
+                cpu_steps(1, xc)
+                probe[tcount] = time.perf_counter() - t1
+            best_t = min(probe, key=probe.get)
+            torch.set_num_threads(best_t)
+            n_timed = max(10, args.cpu_steps)
+            cpu_steps(2, xc)                      # the 2 warm-up steps
+            tc = time.perf_counter()
+            _, cpu_done = cpu_steps(n_timed, xc, budget_s=60.0)
+            tc = time.perf_counter() - tc
+            torch.set_num_threads(ncores)
+            tw = time.perf_counter()
+            cpu_steps(1, xc)                      # warm-up at this thread count
+            tw = time.perf_counter() - tw
+            phys = None
+            if tw < 45.0:
+                tp = time.perf_counter()
+                _, pdone = cpu_steps(n_timed, xc, budget_s=30.0)
+                tp = time.perf_counter() - tp
+                phys = dict(threads=ncores, value=round(pdone / tp, 4), steps=pdone,
+                            sample=f"{pdone} timed steps after 1 warm-up step, 30 s budget, torch.set_num_threads({ncores}) = physical cores")
+            else:
+                phys = dict(threads=ncores, value=round(1.0 / tw, 4), steps=1,
+                            sample=f"one un-warmed step took {tw:.0f} s at torch.set_num_threads({ncores}): not repeated")
+            cpu = dict(value=round(cpu_done / tc, 4), unit="denoise-steps/s", cores=best_t, kind="port",
+                       sample=f"{cpu_done} timed steps (the first of the 250 DDIM steps of the same clip) after 2 warm-up steps at torch.set_num_threads({best_t}), "
+                              f"the best of a 1-step probe over {cand} threads; oracle/ref_unet.py op-for-op PyTorch {torch.__version__} CPU restatement, "
+                              f"fp32; {os.cpu_count()} logical CPUs, {model}",
+                       thread_probe_s_per_step={str(k): round(v, 3) for k, v in probe.items()},
+                       physical_cores_rule=phys)
         # ---- informational only: the same loop with several clips batched on this GPU (amortises the
         # per-launch floor and the weight stream; NOT the BASELINE workload, never `value`)
         batched = None
         if world == 1 and args.batched_clips > 1:
             Bc = args.batched_clips
+            t_sec = time.perf_counter()
             netb = DiffusionWrapper(UNetModel(**BASE_UNET_CONFIG, frames=T, max_batch=Bc)).eval().to(dev)
             netb.load_state_dict(net.state_dict())
             dmb = DDPM(netb, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
@@ -359,12 +396,14 @@ def main():
                            k_attention_tflops=round(afl / ams / 1e9, 2),
                            k_attention_frac_of_f32_mfma_peak=round(afl / ams / 1e9 / MFMA_F32_PEAK_TF, 3))
             del netb, dmb
+            gpu_sections["batched_info"] = time.perf_counter() - t_sec
         # ---- informational only: the steps either side of the loop (BASELINE configs[4]'s decode tail, section 8 f-1/f-2),
         # one 16-frame 256x256 clip through the HIP autoencoder (recipe-filled weights; never part of `value`)
         ae_info = None
         if world == 1 and not args.no_autoencoder and R == 32:
             from moditalker_amd import BASE_AE_DDCONFIG, ViTAutoencoder
             from moditalker_amd import filler
+            t_sec = time.perf_counter()
             ae = ViTAutoencoder(4, BASE_AE_DDCONFIG).eval()
             filler.fill_autoencoder_(ae, seed=77)       # arithmetic recipe; output layers kept out of saturation
             ae = ae.to(dev)
@@ -392,6 +431,7 @@ def main():
                            clip_end_to_end_ms_at_250_steps=round(250 * 1e3 * dt / K + 1e3 * (t_dec + 4 * t_ext), 1),
                            note="4 extracts + 250 steps + decode per 16-frame clip (sample.py:328-386); weights random-init")
             del ae
+            gpu_sections["autoencoder_info"] = time.perf_counter() - t_sec
         attn_roof = dict(bound="mfma", kernel="k_attention", achieved=round(attn["flops"] / (attn["ms"] * 1e-3) / 1e12, 3) if attn["ms"] else 0.0,
                          peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches_per_step=attn["launches"], flops_per_step=attn["flops"])
         attn_roof["frac"] = round(attn_roof["achieved"] / MFMA_F32_PEAK_TF, 4)
@@ -423,6 +463,9 @@ def main():
                                    "base second-stage UNet (132.2M live params), DDIM eta=1, 250-step schedule, B=1 per GPU",
                        "clips": world, "parallelism": f"clip-sharded x{world}, all_gather of latents at the end"},
             "roofline": roofline,
+            # wall seconds of the sections of this process in which the GPU works (a utilisation sampler with a 1 Hz cadence sees little of
+            # them next to the CPU-baseline leg, which keeps the GPU idle for tens of seconds)
+            "gpu_active_s": {"total": round(sum(gpu_sections.values()), 3), **{k: round(v, 3) for k, v in gpu_sections.items()}},
             "cpu_baseline": cpu,
             "step_ms_sum_of_launches": round(step_ms_events, 4),
             "launches_per_step": work["n_launches_step"],

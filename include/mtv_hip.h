@@ -165,6 +165,19 @@ int mtv_debug_attention_qb(int mode);
  * Replaces the same reference code either way: ResBlock convs and the attention blocks' qkv / proj_out at those levels
  * (MToV/models/ddpm/unet.py:178-207, 234, 253).  The parity tests run both. */
 int mtv_debug_deep(int mode);
+/* Variants of the deep levels' dataflow, for plans built after this call (testing aid; every variant meets the parity bars, the
+ * default is the fastest measured): a bit mask of
+ *   MTV_DEEP_OPT_INLAUNCH       a deep tensor that a k_conv / k_pool_down / qkv consumer needs as ONE plain tensor is completed inside
+ *                               the producing launch (slab + ticket, last-arriving K slice) instead of by a k_deep_finalize pass;
+ *   MTV_DEEP_OPT_SLICED_QKV     the attention blocks' qkv conv K-sliced on k_deep_conv (+ a finalize pass) instead of k_conv;
+ *   MTV_DEEP_OPT_UNSLICED_QKV   ... on k_deep_conv with the whole K per workgroup (plain output) where it fits in LDS;
+ *   MTV_DEEP_OPT_NO_FUSED_ATTN  k_attention + a proj_out conv instead of the fused k_deep_attn;
+ * -1 = back to the defaults / the MTV_DEEP_INLAUNCH, MTV_DEEP_QKV, MTV_DEEP_QKV1, MTV_DEEP_NO_ATTN environment variables. */
+#define MTV_DEEP_OPT_INLAUNCH 1
+#define MTV_DEEP_OPT_SLICED_QKV 2
+#define MTV_DEEP_OPT_UNSLICED_QKV 4
+#define MTV_DEEP_OPT_NO_FUSED_ATTN 8
+int mtv_debug_deep_options(int mask);
 
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */
 int mtv_set_eager(mtv_ctx* ctx, int eager);
@@ -175,6 +188,12 @@ int mtv_set_eager(mtv_ctx* ctx, int eager);
  * arithmetic against explicitly constructed index tables for every level of a (res, frames, n_levels)
  * geometry.  Returns 0 when all agree, else 1 + the first level that does not (<0: bad arguments). */
 int mtv_selftest_geometry(int res, int frames, int n_levels);
+/* Host-only self-test (needs no device) of the row tables of the deep levels (csrc/deep.hip: levels of at most 128 tokens per clip,
+ * whose convs stage a whole row group of a channel slice in LDS and address it through a per-launch table of LDS rows): every entry
+ * -- all row groupings, 3x3 and 1x1, same-level and nearest-upsampled source -- is checked against the explicitly constructed
+ * im2col tables (unet.py:178-207 ResBlock convs incl. the Upsample of :531-598).  0 = all agree, else 1 + the first level that
+ * does not (<0: bad arguments). */
+int mtv_selftest_deep(int res, int frames, int n_levels);
 /* The arithmetic itself, for tests: source token of tap (ky, kx in 0..2) at output token `tok` of a level with
  * planes res x res | frames x res | frames x res; up != 0: the source is the (res/2, frames/2) level under a
  * nearest x2 upsample.  Returns -1 for zero padding, else source_token | plane << 28. */

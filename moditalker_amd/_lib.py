@@ -104,6 +104,7 @@ SYMBOLS = [
     ("mtv_debug_attention_b3", C.c_int, [C.c_int]),
     ("mtv_debug_attention_qb", C.c_int, [C.c_int]),
     ("mtv_debug_deep", C.c_int, [C.c_int]),
+    ("mtv_debug_deep_options", C.c_int, [C.c_int]),
     ("mtv_ae_create", C.c_int, [C.POINTER(MtvAeConfig), C.POINTER(_P)]),
     ("mtv_ae_destroy", C.c_int, [_P]),
     ("mtv_ae_set_rotary", C.c_int, [_P, _P, _P]),
@@ -114,6 +115,7 @@ SYMBOLS = [
     ("mtv_xattn_destroy", C.c_int, [_P]),
     ("mtv_xattn_forward", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("mtv_selftest_geometry", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("mtv_selftest_deep", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_gather_index", C.c_int, [C.c_int] * 6),
 ]
 

@@ -199,6 +199,13 @@ static bool table_matches_formula(const std::vector<int>& h, int ntaps, bool upm
 // plan builder
 // =====================================================================================
 static int g_deep_mode = -1;       // mtv_debug_deep: -1 = MTV_DEEP / default (on), 0 = every conv on k_conv, 1 = on
+static int g_deep_opts = -1;       // mtv_debug_deep_options: -1 = the MTV_DEEP_* environment / defaults, else a bit mask (MTV_DEEP_OPT_*)
+static bool deep_opt(int bit, const char* env, bool dflt) {
+    if (g_deep_opts >= 0) return (g_deep_opts & bit) != 0;
+    const char* e = getenv(env);
+    return e ? atoi(e) != 0 : dflt;
+}
+static bool deep_forced_off();     // (a forced legacy tile -- testing aids below -- keeps every conv on the kernel under test)
 
 namespace {
 
@@ -311,7 +318,7 @@ struct Builder {
     bool deep_on(int lvl) const {
         static const bool env = []() { const char* e = getenv("MTV_DEEP"); return !e || atoi(e) != 0; }();
         const bool on = g_deep_mode < 0 ? env : g_deep_mode != 0;
-        return on && B <= 2 && c->lv[lvl].L <= 128;
+        return on && !deep_forced_off() && B <= 2 && c->lv[lvl].L <= 128;
     }
     static DeepSrc dsrc(const Tens& t) { return DeepSrc{t.p, t.slab, t.ks, t.C}; }
     static std::string deep_tag(const DeepArgs& a, const DeepTile& t) {
@@ -395,7 +402,7 @@ struct Builder {
         // emitted so far keep reading the slabs) -- parity-green, and measured no faster: the store -> drain -> ticket -> re-read
         // chain adds 4-4.5 us to the producing launch (conv3 at 32 tokens 8.3 -> 10.1 us, at 128 tokens 15.1 -> 17.1, the
         // attention block 10.6 -> 14.8), the same three dependent round trips as k_conv's split-K completion.
-        static const bool fin_launch = []() { const char* e = getenv("MTV_DEEP_INLAUNCH"); return !(e && atoi(e) != 0); }();
+        const bool fin_launch = !deep_opt(MTV_DEEP_OPT_INLAUNCH, "MTV_DEEP_INLAUNCH", false);
         DeepFin* fn = nullptr;
         std::shared_ptr<void> owner;
         long ntile = 0;
@@ -735,8 +742,8 @@ struct Builder {
         da.B = B; da.L = L.L; da.C = C; da.H = H; da.r = L.r; da.t = L.t; da.whole = whole ? 1 : 0;
         da.scale = 1.0f / std::sqrt(std::sqrt((float)d));
         da.Wp = Wp; da.ldw = ldp; da.bias = bp;
-        static const bool fuse_env = []() { const char* e = getenv("MTV_DEEP_ATTN"); return !e || atoi(e) != 0; }();
-        static const bool deep_qkv_env = []() { const char* e = getenv("MTV_DEEP_QKV"); return e && atoi(e) != 0; }();
+        const bool fuse_env = !deep_opt(MTV_DEEP_OPT_NO_FUSED_ATTN, "MTV_DEEP_NO_ATTN", false);
+        const bool deep_qkv_env = deep_opt(MTV_DEEP_OPT_SLICED_QKV, "MTV_DEEP_QKV", false);
         const bool fused = deep_on(lvl) && fuse_env && deep_attn_configure(da);
         auto emit_fused = [&](const float* qkv_plain, const Tens& xres) -> Tens {
             Tens out;
@@ -801,7 +808,7 @@ struct Builder {
             // the attention needs), GroupNorm statistics computed in the kernel -- where all channels of a row group fit in LDS
             // (32 tokens; 128 tokens per plane group, not with whole-L statistics)
             // (off by default: measured 9.5 us against k_conv's 7.9 at 32 tokens -- 96 workgroups, each staging the whole input)
-            static const bool ks1_env = []() { const char* e = getenv("MTV_DEEP_QKV1"); return e && atoi(e) != 0; }();
+            const bool ks1_env = deep_opt(MTV_DEEP_OPT_UNSLICED_QKV, "MTV_DEEP_QKV1", false);
             DeepArgs dq = deep_args(lvl, 1, 3 * C, bq);
             dq.Cmain = C;
             dq.main[0] = dsrc(x);
@@ -987,6 +994,10 @@ static void parse_force_b3() {
 bool x3_wanted(long rows) {
     parse_force_b3();
     return rows >= X3_MIN_ROWS || g_force_b3[0] > 0;
+}
+static bool deep_forced_off() {
+    parse_force_b3();
+    return g_force_wm > 0 || g_force_lin[0] > 0 || g_force_b3[0] > 0 || getenv("MTV_FORCE_TILE") || getenv("MTV_FORCE_LDS") || getenv("MTV_FORCE_LIN");
 }
 void force_lds_tile(const ConvArgs& a, ConvTile* t) {
     if (g_force_lin[0] == -1) {
@@ -1848,6 +1859,55 @@ int mtv_selftest_geometry(int res, int frames, int n_levels) {
     return 0;
 }
 
+/* Host-only self-test of the deep levels' row tables (deep.hip, deep_rowtab): for every level of at most 128 tokens, every row grouping
+ * and tap count, and the upsampling variant, each table entry must name the source token the explicitly constructed im2col tables
+ * name (or the zero row where they pad).  0 = all agree, else 1 + the level that does not. */
+int mtv_selftest_deep(int res, int frames, int n_levels) {
+    if (res <= 0 || frames <= 0 || n_levels <= 0 || n_levels > 8 || (res >> (n_levels - 1)) <= 0 || (frames >> (n_levels - 1)) <= 0)
+        return fail(MTV_ERR_INVALID, "selftest_deep: bad geometry");
+    const std::vector<Level> lv = make_levels(res, frames, n_levels);
+    for (int l = 0; l < n_levels; ++l) {
+        if (lv[l].L > 128) continue;
+        for (int up = 0; up < 2; ++up) {
+            if (up && l + 1 >= n_levels) continue;
+            const Level& src = up ? lv[l + 1] : lv[l];
+            const std::vector<int> g3 = make_gather3(lv[l], src, up != 0);
+            const std::vector<int> g1 = up ? make_gather_up1(lv[l], src) : std::vector<int>();
+            for (int ntaps : {9, 1})
+                for (int nrg = 1; nrg <= 2; ++nrg) {
+                    DeepArgs a{};
+                    a.ntaps = ntaps; a.r = lv[l].r; a.t = lv[l].t; a.up_main = up; a.B = 1; a.Lout = lv[l].L; a.Lsrc = src.L;
+                    a.N = 64; a.Cmain = 64; a.Cskip = 32; a.KS = 1; a.CSm = 64; a.CSs = 32; a.nrg = nrg;
+                    DeepTile t{};
+                    if (!deep_tile_for(a, &t)) return l + 1;
+                    const std::vector<int> tab = deep_rowtab(a, t);
+                    const int ROWS = 16 * t.RT, SM = a.CSm + 8, SS = a.CSs + 8;
+                    int srows = 0;
+                    for (int rg = 0; rg < nrg; ++rg) {
+                        const int ssz = nrg == 2 ? (rg ? src.L - src.b1 : src.b1) : src.L;
+                        srows = ssz > srows ? ssz : srows;
+                    }
+                    for (int rg = 0; rg < nrg; ++rg) {
+                        const int tok0 = (nrg == 2 && rg) ? lv[l].b1 : 0, ntok = nrg == 2 ? (rg ? lv[l].L - lv[l].b1 : lv[l].b1) : lv[l].L;
+                        const int stok0 = (nrg == 2 && rg) ? src.b1 : 0;
+                        const int* tb = tab.data() + (size_t)rg * (ntaps + 1) * ROWS;
+                        for (int tap = 0; tap < ntaps; ++tap)
+                            for (int ri = 0; ri < ROWS; ++ri) {
+                                int want = -1;
+                                if (ri < ntok) want = ntaps == 9 ? g3[(size_t)tap * lv[l].L + tok0 + ri] : (up ? g1[tok0 + ri] : tok0 + ri);
+                                const int exp_off = want < 0 ? srows * SM : (want - stok0) * SM;
+                                if (tb[tap * ROWS + ri] != exp_off) return l + 1;
+                                if (want >= 0 && (want - stok0 < 0 || want - stok0 >= srows)) return l + 1;     // a tap never leaves its row group
+                            }
+                        for (int ri = 0; ri < ROWS; ++ri)
+                            if (tb[ntaps * ROWS + ri] != (ri < ntok ? ri * SS : ROWS * SS)) return l + 1;
+                    }
+                }
+        }
+    }
+    return 0;
+}
+
 int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up) {
     if (res <= 0 || frames <= 0 || tok < 0 || tok >= res * res + 2 * frames * res || ky < 0 || ky > 2 || kx < 0 || kx > 2)
         return fail(MTV_ERR_INVALID, "debug_gather_index: bad arguments") - 1;   // (-2: distinct from "padding")
@@ -1857,6 +1917,12 @@ int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up)
 int mtv_debug_deep(int mode) {
     if (mode < -1 || mode > 1) return fail(MTV_ERR_INVALID, "mode must be -1 (default), 0 (off) or 1 (on)");
     g_deep_mode = mode;
+    return MTV_OK;
+}
+
+int mtv_debug_deep_options(int mask) {
+    if (mask < -1 || mask > 15) return fail(MTV_ERR_INVALID, "mask must be -1 (environment / defaults) or a combination of MTV_DEEP_OPT_*");
+    g_deep_opts = mask;
     return MTV_OK;
 }
 

@@ -486,3 +486,80 @@ def test_split_bf16_lds_conv_kernel_vs_reference_golden(mt, nt, ks):
         assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
     finally:
         lib.mtv_debug_force_b3(0, 0, 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# deep levels (csrc/deep.hip): K-sliced convs whose consumers add the partial slabs, fused attention + proj_out
+# ----------------------------------------------------------------------------------------------
+def _base_eps_and_sample(lib, names_out=None):
+    g = np.load(os.path.join(GOLDEN, "base.npz"))
+    net = _build(BASE_CFG, 7, max_batch=1)
+    dev = _dev()
+    x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+    worst = 0.0
+    for tv in (999, 500, 0):
+        eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
+        worst = max(worst, _maxabs(eps, g[f"eps_t{tv}"]))
+    if names_out is not None:
+        names_out.extend(p["name"] for p in net.diffusion_model.profile_forward(1, 1, dev, step=True))
+    S = 4
+    dm = DDPM(net, channels=4, image_size=32, sampling_timesteps=S, w=0.0).to(dev)
+    noise = [z.to(dev) for z in filler.noise_list(S, (1, 4, 2048), seed=7, tag=f"base.S{S}")]
+    z = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=noise)
+    return worst, _maxabs(z, g[f"sample_S{S}"])
+
+
+def test_deep_levels_are_on_by_default_and_off_keeps_the_k_conv_path_green():
+    """Default plan of the base UNet at one clip: the convs of levels 2 / 3 (<= 128 tokens) run on k_deep_conv and their attention
+    blocks on the fused k_deep_attn; mtv_debug_deep(0) puts every conv back on k_conv.  Both against the reference golden."""
+    from moditalker_amd import _lib
+    lib = _lib.load()
+    names = []
+    e1, s1 = _base_eps_and_sample(lib, names)
+    assert e1 <= FWD_TOL and s1 <= SAMPLE_TOL, (e1, s1)
+    deep = [n for n in names if n.startswith("conv") and " d" in n.split("[")[-1]]
+    fused = [n for n in names if n.startswith("attn") and "+proj" in n]
+    assert len(deep) >= 28 and len(fused) == 18, (len(deep), len(fused))
+    _lib.check(lib.mtv_debug_deep(0), "mtv_debug_deep")
+    try:
+        names = []
+        e0, s0 = _base_eps_and_sample(lib, names)
+        assert e0 <= FWD_TOL and s0 <= SAMPLE_TOL, (e0, s0)
+        assert not [n for n in names if "+proj" in n or n.startswith("fin")], "deep kernels in a plan built with them switched off"
+    finally:
+        lib.mtv_debug_deep(-1)
+
+
+@pytest.mark.parametrize("mask", [1, 2, 4, 8, 9])
+def test_deep_level_dataflow_variants_vs_reference_golden(mask):
+    """include/mtv_hip.h MTV_DEEP_OPT_*: in-launch completion (slab + ticket) instead of finalize passes, K-sliced / un-sliced qkv on
+    k_deep_conv, k_attention + proj conv instead of the fused kernel -- eps at three timesteps and a 4-step sample vs the
+    reference golden, and two forwards bit-equal (the completion order of the K slices must not matter)."""
+    from moditalker_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_deep_options(mask), "mtv_debug_deep_options")
+    try:
+        e, s = _base_eps_and_sample(lib)
+        assert e <= FWD_TOL and s <= SAMPLE_TOL, (mask, e, s)
+        net = _build(SHALLOW_CFG, 12)
+        dev = _dev()
+        x, cond, ic = filler.synthetic_inputs(2, 32, 16, seed=12, tag="shallow")
+        t = torch.tensor([321, 9], device=dev)
+        a = net(x.to(dev), cond.to(dev), ic.to(dev), t)
+        for _ in range(5):
+            assert torch.equal(net(x.to(dev), cond.to(dev), ic.to(dev), t), a)
+    finally:
+        lib.mtv_debug_deep_options(-1)
+
+
+def test_deep_kernels_against_cpu_conv_and_attention():
+    """tools/ubench/deep_bench (built by __graft_entry__.build): k_deep_conv on 19 shapes (3x3 / 1x1, concatenated sources, fused skip
+    conv, residuals in slabs, upsampled sources, both row groupings, ragged planes, two clips, the base model's full-size shapes)
+    and k_deep_attn on 9 (1-D / per-plane, head dims 16 / 32 / 64, ragged) against plain CPU restatements in double."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "ubench", "deep_bench")
+    if not os.path.exists(exe):
+        pytest.skip("tools/ubench/deep_bench not built (python -c 'import __graft_entry__ as g; g.build()')")
+    for mode, ok in (("check", "CHECK OK"), ("attn", "ATTN CHECK OK")):
+        out = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and ok in out.stdout, out.stdout[-2000:] + out.stderr[-500:]

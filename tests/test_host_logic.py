@@ -232,3 +232,14 @@ def test_committed_tile_table_is_well_formed():
         else:                             # k_conv<MT, NT, NW>
             assert mt in (1, 2, 4) and nt in (1, 2, 4) and nw in (1, 2, 4, 8, 16) and ks in (1, 2, 4, 8, 16) and xm in (0, 1), line
     assert len(seen) >= 150 and n48 >= 20 and all(k in seen for k in twins)
+
+
+@pytest.mark.parametrize("R,T,levels", [(32, 16, 4), (64, 16, 4), (8, 4, 3), (16, 8, 4), (24, 8, 3), (16, 8, 2), (4, 2, 1)])
+def test_deep_level_row_tables_match_im2col_tables(R, T, levels):
+    """csrc/deep.hip: the convs of the levels of <= 128 tokens stage a row group of a channel slice in LDS and address it through
+    a host-built table of LDS rows (deep_rowtab).  Every entry -- both row groupings, 3x3 and 1x1, same-level and
+    nearest-upsampled source -- against the explicitly constructed im2col tables (host only, through the C ABI)."""
+    from moditalker_amd import _lib
+    lib = _lib.load()
+    assert lib.mtv_selftest_deep(R, T, levels) == 0
+    assert lib.mtv_selftest_deep(0, 4, 2) < 0            # bad arguments are an error, not a pass

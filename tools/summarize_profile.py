@@ -38,6 +38,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("trace")
 ap.add_argument("--fetch")
 ap.add_argument("--write")
+
+
+def family(k):
+    # the conv family = k_conv / k_conv_lds / k_conv_x3 / k_lin and the K-sliced k_deep_conv of the <= 128-token levels (csrc/deep.hip)
+    if k.startswith("k_conv") or k.startswith("k_deep_conv") or k.startswith("k_lin"):
+        return "k_conv<*> + k_deep_conv<*>"
+    if k.startswith("k_attention"):
+        return "k_attention<*>"
+    return k
+
+
 ap.add_argument("--launches", type=int, required=True, help="dispatches per sampler step (bench.py: launches_per_step)")
 ap.add_argument("--skip", type=int, default=15, help="steps to skip at the start of the run")
 a = ap.parse_args()
@@ -64,7 +75,7 @@ tot = sum(v[1] for v in agg.values())
 fam = collections.defaultdict(lambda: [0, 0.0])
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:34s} {c / n:13.1f} {t / n / 1e3:10.1f} {t / c / 1e3:8.2f} {100 * t / tot:6.1f}")
-    f = "k_conv<*>" if k.startswith("k_conv") else ("k_attention<*>" if k.startswith("k_attention") else k)
+    f = family(k)
     fam[f][0] += c
     fam[f][1] += t
 print("# by family")
@@ -79,7 +90,7 @@ for label, path in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
     for s, e in sel2:
         for r in rows2[s:e]:
             k = short(r["Kernel_Name"])
-            f = "k_conv<*>" if k.startswith("k_conv") else ("k_attention<*>" if k.startswith("k_attention") else k)
+            f = family(k)
             fam2[f] += float(r["Counter_Value"])
     print(f"# {label} per step, raw counter (KB -> MB); gfx950 FETCH_SIZE reads 1/2 of wide streaming reads (MI355X_MICROARCH.md)")
     for k, v in sorted(fam2.items(), key=lambda kv: -kv[1])[:6]:
