@@ -149,6 +149,10 @@ int mtv_debug_force_b3(int mt, int nt, int ks);
  * unet.py:234,253) on the lean kernel k_lin<mt, nt, nwv> (wave tile 16 mt x 16 nt, nwv waves side by side along the
  * output channels, whole K per wave; csrc/lin.hip) instead of the tuned choice; mt = 0 switches it off again. */
 int mtv_debug_force_lin(int mt, int nt, int nwv);
+/* Testing aid: plans built after this call run every eligible 3x3 convolution (ResBlock in_layers / out_layers, unet.py:131-167) on
+ * the window-staged kernel k_conv_win<mt, nt> (row tile 16 mt x column tile 16 nt; the transformed input rows of the tile and their
+ * halo staged in LDS once, csrc/deep.hip) instead of the tuned choice; mt = 0 switches it off again. */
+int mtv_debug_force_win(int mt, int nt);
 /* Which attention core the UNet's self-attention launches take (head dim 16 / 32 / 64; process-wide, takes effect at the
  * next launch / graph capture): 0 = the exact-f32 core k_attention everywhere (the default: it is the faster one on
  * MI355X at every shape measured), 1 = the split-bf16 core k_attention_b3 (csrc/attn_b3.hip) on every eligible launch,

@@ -1224,6 +1224,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
 }
 
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
+    if (t.NW == 80) return conv_win_smem_bytes(a, t);
     if (t.NW == 64) return lin_smem_bytes(a);
     if (t.NW == 48) return conv_x3_smem_bytes(a, t);
     if (t.NW == 32) return lds_bytes_tiled(t.MT, t.NT, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
@@ -1320,6 +1321,13 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
         a.xmap = 0;            // no padding blocks: every block of the grid takes part in the step hand-over
     }
     hipError_t e = hipErrorInvalidValue;
+    if (t.NW == 80) {            // window-staged 3x3 kernel of the large levels (deep.hip: k_conv_win)
+        if (conv_win_eligible(a, t.MT, t.NT)) return launch_conv_win(a, t, s);
+        t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);   // (statistics targets are
+        t.KS = 1;                                                                                                       // attached after the op is created)
+        a.KS = 1;
+        a.xmap = t.XM;
+    }
     if (t.NW == 48) {            // split-bf16 kernels for large token counts (conv_x3.hip: elementwise pass + gathering GEMM)
         if (conv_x3_eligible(a) && a.x3) return launch_conv_x3(a, t, s);
         t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);

@@ -190,38 +190,45 @@ __device__ __forceinline__ bool deep_fin_arrive(const DeepFin& f, int tile, int 
     __syncthreads();
     return *flag != 0;
 }
-__device__ __forceinline__ void deep_fin_stat(const DeepFin& f, float* scratch, int tok, int n, const f32x4& v) {
+// (consumer `t` of the tensor: its group size / channel offset BY VALUE -- a run-time index into a stat[] array inside a local struct
+// would put the struct in scratch memory)
+__device__ __forceinline__ void deep_stat_one(const StatOut so, int t, const SegInfo seg, float* scratch, int tok, int n, const f32x4& v) {
     double* st = reinterpret_cast<double*>(scratch + 4);
-    const int sg = tok >= f.seg.b2 ? 2 : (tok >= f.seg.b1 ? 1 : 0);
-    for (int t = 0; t < f.nstat; ++t) {
-        const int gs = f.stat[t].gs;
-        if ((gs & 3) == 0) {
-            const int g = (f.stat[t].coff + n) / gs;
-            atomicAdd(&st[((t * 96) + sg * 32 + g) * 2], ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]));
-            atomicAdd(&st[((t * 96) + sg * 32 + g) * 2 + 1], ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]));
-        } else {
+    const int sg = tok >= seg.b2 ? 2 : (tok >= seg.b1 ? 1 : 0);
+    const int gs = so.gs;
+    if ((gs & 3) == 0) {
+        const int g = (so.coff + n) / gs;
+        atomicAdd(&st[((t * 96) + sg * 32 + g) * 2], ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]));
+        atomicAdd(&st[((t * 96) + sg * 32 + g) * 2 + 1], ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]));
+    } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int g = (f.stat[t].coff + n + k) / gs;
-                atomicAdd(&st[((t * 96) + sg * 32 + g) * 2], (double)v[k]);
-                atomicAdd(&st[((t * 96) + sg * 32 + g) * 2 + 1], (double)v[k] * v[k]);
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int g = (so.coff + n + k) / gs;
+            atomicAdd(&st[((t * 96) + sg * 32 + g) * 2], (double)v[k]);
+            atomicAdd(&st[((t * 96) + sg * 32 + g) * 2 + 1], (double)v[k] * v[k]);
         }
     }
 }
-__device__ __forceinline__ void deep_fin_flush(const DeepFin& f, float* scratch, int b, int tid) {
-    if (!f.nstat) return;
-    __syncthreads();
+__device__ __forceinline__ void deep_stat_flush_one(const StatOut so, int t, unsigned cstride, const float* scratch, int b, int tid) {
     const double* st = reinterpret_cast<const double*>(scratch + 4);
-    for (int e = tid; e < f.nstat * 96; e += DEEP_NTH) {
-        const int t = e / 96, r2 = e - t * 96;
-        const double sx = st[e * 2], sy = st[e * 2 + 1];
+    for (int e = tid; e < 96; e += DEEP_NTH) {
+        const double sx = st[(t * 96 + e) * 2], sy = st[(t * 96 + e) * 2 + 1];
         if (sy != 0.0) {
-            double* dst = f.stat[t].sums + (size_t)(blockIdx.x & (STAT_COPIES - 1)) * f.stat_cstride + ((size_t)b * 96 + r2) * 2;
+            double* dst = so.sums + (size_t)(blockIdx.x & (STAT_COPIES - 1)) * cstride + ((size_t)b * 96 + e) * 2;
             atomicAdd(dst, sx);
             atomicAdd(dst + 1, sy);
         }
     }
+}
+__device__ __forceinline__ void deep_fin_stat(const DeepFin& f, float* scratch, int tok, int n, const f32x4& v) {
+    if (f.nstat > 0) deep_stat_one(f.stat[0], 0, f.seg, scratch, tok, n, v);
+    if (f.nstat > 1) deep_stat_one(f.stat[1], 1, f.seg, scratch, tok, n, v);
+}
+__device__ __forceinline__ void deep_fin_flush(const DeepFin& f, float* scratch, int b, int tid) {
+    if (!f.nstat) return;
+    __syncthreads();
+    deep_stat_flush_one(f.stat[0], 0, f.stat_cstride, scratch, b, tid);
+    if (f.nstat > 1) deep_stat_flush_one(f.stat[1], 1, f.stat_cstride, scratch, b, tid);
 }
 constexpr int DEEP_FIN_FLOATS = 4 + 2 * 96 * 2 * 2;      // flag + [2 consumers][96][2] doubles
 
@@ -961,6 +968,331 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     DEEP_STAMP(9);
 }
 
+
+// =====================================================================================
+// k_conv_win: 3x3 conv of the LARGE levels (512 / 2048 tokens) with the transformed input window of a row tile staged in LDS
+// =====================================================================================
+// Same arguments, same results layout and same statistics hand-over as k_conv (conv.hip: ConvArgs; GroupNorm statistics of the
+// input come from the producers' site table, those of the output go to the consumers'), one difference in the K loop: the
+// 16 MT output rows of a workgroup and their 3x3 halo -- a contiguous range of source tokens, at most 16 MT + 2 r + 2 rows --
+// are normalised / FiLM-ed / SiLU-ed ONCE and parked in LDS, and all nine taps read their A fragments from there
+// (BASELINE.json north_star: "LDS-staged input tiles").  k_conv transforms every element once per tap AND per column tile in
+// the K loop, on the VALU that the exact-f32 MFMA blocks (conv.hip section 3.1: K loop 630 us per step for 364 us of MFMA).
+// Workgroup = (clip, row tile, column tile of 16 NT channels), 512 threads; the 8 waves split K (chunk c -> wave c mod 8), B
+// fragments straight from k_conv's weight layout (lane (j, q) loads W[c0 + 4q + s][n0 + NT j ..+NT-1]: output channel
+// n0 + NT j + nb sits at lane j of column block nb), summed in wave order through LDS.
+// Source-token window of the row tile that starts at output token tok0 (a superset of what its taps touch, one contiguous range:
+// planes are contiguous and a 3x3 tap moves at most one image row + one token).  Host (LDS sizing) and device use the same code.
+__host__ __device__ inline void conv_win_window(int r, int t, bool up, int Lout, int tok0, int rows, int* lo, int* n) {
+    const int b1 = r * r, b2 = b1 + t * r, L = b2 + t * r;
+    const int first = tok0, last = (tok0 + rows < Lout ? tok0 + rows : Lout) - 1;
+    const int pf = first >= b2 ? 2 : (first >= b1 ? 1 : 0), pl = last >= b2 ? 2 : (last >= b1 ? 1 : 0);
+    const int sf = pf == 0 ? 0 : (pf == 1 ? b1 : b2), el = pl == 0 ? b1 : (pl == 1 ? b2 : L);
+    if (!up) {
+        const int a0 = first - r - 1, a1 = last + r + 1;
+        const int wlo = a0 > sf ? a0 : sf, whi = a1 < el - 1 ? a1 : el - 1;
+        *lo = wlo;
+        *n = whi - wlo + 1;
+        return;
+    }
+    const int rs = r >> 1, ts = t >> 1, b1s = rs * rs, b2s = b1s + ts * rs;
+    const int hl = pl == 0 ? r : t;
+    const int sl = pl == 0 ? 0 : (pl == 1 ? b1 : b2);
+    int yf = (first - sf) / r - 1, yl = (last - sl) / r + 1;
+    yf = yf < 0 ? 0 : yf;
+    yl = yl > hl - 1 ? hl - 1 : yl;
+    const int of = pf == 0 ? 0 : (pf == 1 ? b1s : b2s), ol = pl == 0 ? 0 : (pl == 1 ? b1s : b2s);
+    const int wlo = of + (yf >> 1) * rs, whi = ol + (yl >> 1) * rs + rs - 1;
+    *lo = wlo;
+    *n = whi - wlo + 1;
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
+    touch_kernargs<(int)sizeof(ConvArgs)>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, COLS = 16 * NT, G = 3;
+    constexpr int MAXR = 12;                               // window rows in flight per thread (first pass)
+    typedef float bvec __attribute__((ext_vector_type(NT)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = deep_usgpr(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    // block -> (column tile, clip, row tile): column tiles of one row tile are 1 / tiles_n of the grid apart, so with a multiple of 8
+    // row tiles they share an XCD (and the window they all stage)
+    const int blk = deep_usgpr((int)blockIdx.x);
+    const int ct = deep_usgpr(FDiv{a.inv_Bt}(blk, a.Bt));
+    const int brt = blk - ct * a.Bt;
+    const int b = deep_usgpr(FDiv{a.inv_tiles_per_b}(brt, a.tiles_per_b));
+    const int tok0 = (brt - b * a.tiles_per_b) * ROWS, n0 = ct * COLS;
+    const int Cmain = a.Cmain, Cskip = a.Cskip;
+    const int SW = Cmain + DEEP_PAD, SK = Cskip + DEEP_PAD;
+    const int wcap = a.rec_cap;                            // window capacity in rows (host); row wcap of the window = zeros
+    float* const lwin = smem;                              // [wcap + 1][SW]
+    float* const lraw = lwin + (wcap + 1) * SW;            // [ROWS + 1][SK]: raw rows of the fused 1x1 skip conv
+    int* const idx = reinterpret_cast<int*>(lraw + (Cskip ? (ROWS + 1) * SK : 0));       // [9][ROWS] float offsets into lwin | [ROWS] into lraw
+    double* const sdp = reinterpret_cast<double*>(idx + 10 * ROWS);                    // [96][2] input statistics, copies added up
+    float2* const s_mr = reinterpret_cast<float2*>(sdp + 192);                         // [3][32] (mean, rstd)
+    const bool do_gn = a.gn.sums != nullptr;
+    int wlo, wn;
+    conv_win_window(a.geo_r, a.geo_t, a.geo_main == 2, a.Lout, tok0, ROWS, &wlo, &wn);
+    wn = wn < wcap ? wn : wcap;                            // (<= wcap by construction: conv_win_layout takes the maximum over the tiles)
+    // ---- every request of the launch, oldest first = needed first: input statistics, GroupNorm vectors of this thread's channel quad,
+    // its window rows (RAW registers: nothing loaded is used before the weights are requested), raw skip rows, weights
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 vraw[STAT_COPIES];
+    if (do_gn && tid < 96) {
+#pragma unroll
+        for (int k = 0; k < STAT_COPIES; ++k) vraw[k] = *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)tid * 2);
+    }
+    const int QW = Cmain >> 2, RP = DEEP_NTH / QW;         // staging map: thread -> quad column qd of rows rl, rl + RP, ...
+    const int qd = tid % QW, rl = tid / QW;
+    const bool stager = rl < RP;
+    const int c4 = 4 * qd, C0 = a.C[0];
+    const float* film = (do_gn && a.gn.film) ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = ga, f1 = ga, f2 = ga;
+    if (do_gn && stager) {
+        ga = *reinterpret_cast<const f32x4*>(a.gn.gamma + c4);
+        be = *reinterpret_cast<const f32x4*>(a.gn.beta + c4);
+        f1 = *reinterpret_cast<const f32x4*>((film ? film : a.gn.gamma) + c4);           // (selected at use, not at load: no early wait)
+        f2 = *reinterpret_cast<const f32x4*>((film ? film + Cmain : a.gn.beta) + c4);
+    }
+    const float* xcol = c4 < C0 ? a.src[0] + ((size_t)b * a.Lsrc + wlo) * C0 + c4 : a.src[1] + ((size_t)b * a.Lsrc + wlo) * a.C[1] + (c4 - C0);
+    const int xstride = c4 < C0 ? C0 : a.C[1];
+    f32x4 xr[MAXR];
+    if (stager) {
+#pragma unroll
+        for (int u = 0; u < MAXR; ++u) {
+            if (u * RP >= wn) break;                                  // (uniform)
+            const int row = rl + u * RP;
+            xr[u] = *reinterpret_cast<const f32x4*>(xcol + (size_t)(row < wn ? row : 0) * xstride);
+        }
+    }
+    f32x4 sraw = {0.f, 0.f, 0.f, 0.f};
+    const int QS = Cskip >> 2, C2 = a.C[2];
+    const bool has_sraw = Cskip && tid < ROWS * QS && tok0 + tid / (QS > 0 ? QS : 1) < a.Lout;
+    if (has_sraw) {
+        const int row = tid / QS, c = 4 * (tid - row * QS);
+        const float* p = c < C2 ? a.src[2] + ((size_t)b * a.Lskip + tok0 + row) * C2 + c : a.src[3] + ((size_t)b * a.Lskip + tok0 + row) * a.C[3] + (c - C2);
+        sraw = *reinterpret_cast<const f32x4*>(p);
+    }
+    const int cpt = a.cpt, nmain_ch = 9 * cpt, nch = nmain_ch + (Cskip >> 4);
+    const int n_it = (nch + 7) >> 3;
+    const int wrows = 9 * Cmain + Cskip;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, wrows * a.ldw * 4, 0x00020000);
+    const int wlane = ((4 * q) * a.ldw + n0 + NT * i) * 4;
+    bvec bq[2][G][4];
+    auto wload = [&](bvec (&dst)[G][4], int k0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int c = wave + 8 * (k0 + g);
+            // W row of the chunk's first channel: tap-major over the concatenated main channels, then the skip channels (k_conv's
+            // order of rows); a chunk past the end reads out of range = zeros
+            int krow = 9 * Cmain + (c - nmain_ch) * 16;
+            if (c < nmain_ch) { const int tap = FDiv{a.inv_cpt}(c, cpt); krow = tap * Cmain + (c - tap * cpt) * 16; }
+            const int soff = c < nch ? krow * a.ldw * 4 : 0x7F000000;
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                if constexpr (NT == 4) dst[g][sI] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + sI * a.ldw * 4, soff, 0));
+                else dst[g][sI] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, wlane + sI * a.ldw * 4, soff, 0));
+            }
+        }
+    };
+    wload(bq[0], 0);
+    wload(bq[1], G);
+    // ---- while they fly: row table (LDS float offsets: window row of every (tap, output row), the zero row for padding), zero rows
+    for (int e = tid; e < 9 * ROWS; e += DEEP_NTH) {
+        const int tap = e / ROWS, ri = e - tap * ROWS;
+        const int tok = tok0 + ri;
+        int src = -1;
+        if (tok < a.Lout) {
+            const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+            const int g = geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, ky, tap - 3 * ky, a.geo_main == 2);
+            src = g < 0 ? -1 : (g & 0x0FFFFFFF) - wlo;
+        }
+        idx[e] = (src < 0 || src >= wn) ? wcap * SW : src * SW;
+    }
+    for (int e = tid; e < ROWS; e += DEEP_NTH) idx[9 * ROWS + e] = tok0 + e < a.Lout ? e * SK : ROWS * SK;
+    for (int e = tid; e < Cmain; e += DEEP_NTH) lwin[wcap * SW + e] = 0.f;
+    if (Cskip)
+        for (int e = tid; e < Cskip; e += DEEP_NTH) lraw[ROWS * SK + e] = 0.f;
+    if (do_gn && tid < 96) {                                       // input statistics: the 8 copies added up (first use of a loaded value)
+        f64x2 v0 = vraw[0];
+#pragma unroll
+        for (int k = 1; k < STAT_COPIES; ++k) v0 += vraw[k];
+        sdp[2 * tid] = v0[0];
+        sdp[2 * tid + 1] = v0[1];
+    }
+    __syncthreads();
+    if (do_gn && tid < 96) {
+        const int sg = tid >> 5, g = tid & 31;
+        double sx, sy, inv_n;
+        if (a.gn.whole) {
+            sx = (sdp[2 * g] + sdp[2 * (32 + g)]) + sdp[2 * (64 + g)];
+            sy = (sdp[2 * g + 1] + sdp[2 * (32 + g) + 1]) + sdp[2 * (64 + g) + 1];
+            inv_n = a.gn.inv_n[3];
+        } else {
+            sx = sdp[2 * tid];
+            sy = sdp[2 * tid + 1];
+            inv_n = a.gn.inv_n[sg];
+        }
+        const double mean = sx * inv_n;
+        double var = sy * inv_n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_mr[tid] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
+    }
+    if (do_gn) __syncthreads();
+    // ---- transform this thread's window rows ONCE (y = x A + B, SiLU) and park them; then the raw skip rows
+    if (stager) {
+        const bool act = a.gn.act != 0;
+        const SegInfo ss = a.seg_src;
+        int cur = -1;
+        f32x4 A = {1.f, 1.f, 1.f, 1.f}, Bc = {0.f, 0.f, 0.f, 0.f};
+        auto transform = [&](int row, f32x4 y) {
+            if (do_gn) {
+                const int tk = wlo + row;
+                const int sg = tk >= ss.b2 ? 2 : (tk >= ss.b1 ? 1 : 0);
+                if (sg != cur) {                                   // (rows ascend: at most three times)
+                    cur = sg;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float2 mr = s_mr[sg * 32 + FDiv{a.gn.inv_gs}(c4 + k, a.gn.gs)];
+                        const float sc = mr.y * ga[k];
+                        const float bi = be[k] - sc * mr.x;
+                        const float s1 = film ? 1.0f + f1[k] : 1.0f, sh = film ? f2[k] : 0.f;
+                        A[k] = sc * s1;
+                        Bc[k] = fmaf(bi, s1, sh);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = fmaf(y[k], A[k], Bc[k]);
+                    y[k] = act ? deep_silu(t) : t;
+                }
+            }
+            *reinterpret_cast<f32x4*>(lwin + row * SW + c4) = y;
+        };
+#pragma unroll
+        for (int u = 0; u < MAXR; ++u) {
+            if (u * RP >= wn) break;
+            const int row = rl + u * RP;
+            if (row < wn) transform(row, xr[u]);
+        }
+        for (int row = rl + MAXR * RP; row < wn; row += RP)       // (windows taller than MAXR RP rows: requested late, behind the weights)
+            transform(row, *reinterpret_cast<const f32x4*>(xcol + (size_t)row * xstride));
+    }
+    if (has_sraw) {
+        const int row = tid / QS, c = 4 * (tid - row * QS);
+        *reinterpret_cast<f32x4*>(lraw + row * SK + c) = sraw;
+    }
+    if (Cskip)
+        for (int e = tid + DEEP_NTH; e < ROWS * QS; e += DEEP_NTH) {
+            const int row = e / QS, c = 4 * (e - row * QS);
+            if (tok0 + row < a.Lout) {
+                const float* p = c < C2 ? a.src[2] + ((size_t)b * a.Lskip + tok0 + row) * C2 + c : a.src[3] + ((size_t)b * a.Lskip + tok0 + row) * a.C[3] + (c - C2);
+                *reinterpret_cast<f32x4*>(lraw + row * SK + c) = *reinterpret_cast<const f32x4*>(p);
+            }
+        }
+    __syncthreads();
+    // ---- K loop: A fragments from the window (one chunk ahead), weights of iteration k + 2G replace those of k
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        auto loadA = [&](int k, f32x4 (&av)[MT]) {
+            int c = wave + 8 * k;
+            c = c < nch ? c : nch - 1;
+            const bool sk = c >= nmain_ch;
+            const int tap = sk ? 9 : FDiv{a.inv_cpt}(c, cpt);
+            const int cc = sk ? c - nmain_ch : c - tap * cpt;
+            const float* ab = (sk ? lraw : lwin) + cc * 16 + 4 * q;
+            const int* ip = idx + tap * ROWS + i;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(ab + ip[16 * mt]);
+        };
+        auto mma = [&](const f32x4 (&av)[MT], const bvec (&w)[4]) {
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][sI], w[sI][nb], acc[mt][nb], 0, 0, 0);
+        };
+        f32x4 avA[MT], avB[MT];
+        auto step = [&](int kk, int par, const bvec (&w)[4]) {
+            if (par) { loadA(kk + 1, avA); mma(avB, w); }
+            else { loadA(kk + 1, avB); mma(avA, w); }
+        };
+        loadA(0, avA);
+        int k = 0;
+        for (; k + 2 * G <= n_it; k += 2 * G) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) step(k + g, g & 1, bq[0][g]);
+            wload(bq[0], k + 2 * G);
+#pragma unroll
+            for (int g = 0; g < G; ++g) step(k + G + g, (G + g) & 1, bq[1][g]);
+            wload(bq[1], k + 3 * G);
+        }
+        const int rem = n_it - k;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (g < rem) step(k + g, g & 1, bq[0][g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (G + g < rem) step(k + G + g, (G + g) & 1, bq[1][g]);
+    }
+    __syncthreads();
+    // ---- the eight partial tiles -> (row, col) images (lane (i, q) holds, for row 4q + r, the NT consecutive columns NT i ..)
+    constexpr int LDR = COLS + 4;
+    float* const red = smem;
+    {
+        float* my = red + (size_t)wave * ROWS * LDR + (4 * q) * LDR + NT * i;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                bvec t;
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) t[nb] = acc[mt][nb][rr];
+                *reinterpret_cast<bvec*>(my + (16 * mt + rr) * LDR) = t;
+            }
+    }
+    __syncthreads();
+    // ---- epilogue: bias / per-clip bias / residual, coalesced store, statistics of the output for its consumers
+    float* scratch = red + 8 * ROWS * LDR;                   // statistics slots (deep_stat_one layout: 4 floats, then [2][96][2] doubles)
+    {
+        double* st = reinterpret_cast<double*>(scratch + 4);
+        for (int e = tid; e < a.nstat * 96 * 2; e += DEEP_NTH) st[e] = 0.0;
+        if (a.nstat) __syncthreads();
+    }
+    constexpr int QPR = COLS / 4;
+    for (int e = tid; e < ROWS * QPR; e += DEEP_NTH) {
+        const int rr = e / QPR, cq = e - rr * QPR;
+        const int tok = tok0 + rr, n = n0 + 4 * cq;
+        if (tok >= a.Lout) continue;
+        const float* rp = red + rr * LDR + 4 * cq;
+        f32x4 v = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
+        v += *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (a.bias2) v += *reinterpret_cast<const f32x4*>(a.bias2 + n);
+        if (a.bias_b) v += *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + n);
+        if (a.res) {
+            const int rs = a.geo_skip ? (geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
+            v += *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + rs) * a.N + n);
+        }
+        *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
+        if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, tok, n, v);
+        if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, tok, n, v);
+    }
+    if (a.nstat) {
+        __syncthreads();
+        deep_stat_flush_one(a.stat[0], 0, a.stat_cstride, scratch, b, tid);
+        if (a.nstat > 1) deep_stat_flush_one(a.stat[1], 1, a.stat_cstride, scratch, b, tid);
+    }
+}
+
 // =====================================================================================
 // host side
 // =====================================================================================
@@ -1139,7 +1471,9 @@ hipError_t deep_init_attrs() {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    const void* fa[] = {reinterpret_cast<const void*>(&k_deep_attn<16>), reinterpret_cast<const void*>(&k_deep_attn<32>), reinterpret_cast<const void*>(&k_deep_attn<64>)};
+    const void* fa[] = {reinterpret_cast<const void*>(&k_deep_attn<16>), reinterpret_cast<const void*>(&k_deep_attn<32>), reinterpret_cast<const void*>(&k_deep_attn<64>),
+                        reinterpret_cast<const void*>(&k_conv_win<1, 4>), reinterpret_cast<const void*>(&k_conv_win<1, 2>),
+                        reinterpret_cast<const void*>(&k_conv_win<2, 2>)};
     for (const void* f : fa) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1206,6 +1540,65 @@ hipError_t launch_deep_attn(const DeepAttnArgs& a0, hipStream_t s) {
     else if (d == 64) hipLaunchKernelGGL((k_deep_attn<64>), grid, dim3(DEEP_NTH), smem, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
+}
+
+// ---- k_conv_win (ConvTile{MT, NT, NW = 80, KS = 1, XM = 0}) ----
+static size_t conv_win_layout(const ConvArgs& a, int MT, int NT, int* wcap_out) {
+    const int ROWS = 16 * MT, COLS = 16 * NT;
+    int wcap = 1;                                           // the tallest window of any row tile (same arithmetic as the kernel)
+    for (int tok0 = 0; tok0 < a.Lout; tok0 += ROWS) {
+        int lo, n;
+        conv_win_window(a.geo_r, a.geo_t, a.geo_main == 2, a.Lout, tok0, ROWS, &lo, &n);
+        if (lo < 0 || lo + n > a.Lsrc) return (size_t)1 << 30;          // (never: the window is clamped to its planes)
+        wcap = n > wcap ? n : wcap;
+    }
+    if (wcap_out) *wcap_out = wcap;
+    size_t fl = (size_t)(wcap + 1) * (a.Cmain + DEEP_PAD);
+    if (a.Cskip) fl += (size_t)(ROWS + 1) * (a.Cskip + DEEP_PAD);
+    fl += 10 * ROWS + 384 + 192;                                        // row table | statistics (doubles) | (mean, rstd)
+    const size_t red = (size_t)8 * ROWS * (COLS + 4) + DEEP_FIN_FLOATS;
+    return (fl > red ? fl : red) * 4 + 64;
+}
+bool conv_win_eligible(const ConvArgs& a, int MT, int NT) {
+    if (!((MT == 1 && (NT == 2 || NT == 4)) || (MT == 2 && NT == 2))) return false;       // (2 x 4 spills at 512 threads)
+    if (a.ntaps != 9 || (a.geo_main != 1 && a.geo_main != 2) || a.out_cm || a.ddim || a.N % (16 * NT) || (a.Cmain & 15) || (a.Cskip & 15) || a.Cmain > 2048) return false;
+    if (a.nmain == 2 && (a.C[0] & 3)) return false;
+    if (a.nskip == 2 && (a.C[2] & 3)) return false;
+    if (a.res && a.gather_skip && !a.geo_skip) return false;               // (residual rows by table only: not here)
+    for (int t = 0; t < a.nstat; ++t)
+        if (a.stat[t].coff & 3) return false;
+    if ((long)(9 * a.Cmain + a.Cskip) * a.ldw * 4 >= 0x7F000000L) return false;
+    return conv_win_layout(a, MT, NT, nullptr) <= 160 * 1024;
+}
+size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_win_layout(a, t.MT, t.NT, nullptr); }
+
+template <int MT, int NT>
+static hipError_t conv_win_launch_t(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    if (!conv_win_eligible(a, MT, NT)) return hipErrorInvalidValue;
+    const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT), tiles_n = a.N / (16 * NT);
+    a.KS = 1;
+    a.xmap = 0;
+    a.tiles_per_b = tiles;
+    a.tiles_n = tiles_n;
+    a.Bt = a.B * tiles;
+    a.inv_tiles_per_b = 1.0f / (float)tiles;
+    a.inv_Bt = 1.0f / (float)a.Bt;
+    a.cpt = a.Cmain / 16;
+    a.inv_cpt = 1.0f / (float)a.cpt;
+    a.geo_inv_r = 1.0f / (float)a.geo_r;
+    int wcap = 0;
+    const size_t smem = conv_win_layout(a, MT, NT, &wcap);
+    a.rec_cap = wcap;
+    if ((long)a.Bt * tiles_n >= (1L << 21)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_conv_win<MT, NT>), dim3((unsigned)(a.Bt * tiles_n)), dim3(DEEP_NTH), smem, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s) {
+    if (t.MT == 1 && t.NT == 4) return conv_win_launch_t<1, 4>(a, s);
+    if (t.MT == 1 && t.NT == 2) return conv_win_launch_t<1, 2>(a, s);
+    if (t.MT == 2 && t.NT == 2) return conv_win_launch_t<2, 2>(a, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_deep_finalize(const DeepFinArgs& a, hipStream_t s) {

@@ -978,6 +978,7 @@ struct Builder {
 // LDS-tiled kernel k_conv_lds<WM, WN>; a conv that turns out not to be eligible at launch falls back (launch_conv)
 static int g_force_wm = -1, g_force_wn = 0;
 static int g_force_b3[3] = {-1, 0, 1};       // MTV_FORCE_B3="MT,NT[,KS]" (or mtv_debug_force_b3): every eligible conv on the split-bf16 kernel k_conv_x3<MT, NT>
+static int g_force_win[2] = {-1, 0};        // MTV_FORCE_WIN="MT,NT" (or mtv_debug_force_win): every eligible 3x3 conv on k_conv_win<MT, NT>
 static int g_force_lin[3] = {-1, 0, 0};     // MTV_FORCE_LIN="MT,NT,NWV" (or mtv_debug_force_lin): every eligible 1x1 conv on k_lin<MT, NT, NWV>
 static void parse_force_b3() {
     if (g_force_b3[0] != -1) return;
@@ -997,7 +998,8 @@ bool x3_wanted(long rows) {
 }
 static bool deep_forced_off() {
     parse_force_b3();
-    return g_force_wm > 0 || g_force_lin[0] > 0 || g_force_b3[0] > 0 || getenv("MTV_FORCE_TILE") || getenv("MTV_FORCE_LDS") || getenv("MTV_FORCE_LIN");
+    return g_force_wm > 0 || g_force_lin[0] > 0 || g_force_b3[0] > 0 || getenv("MTV_FORCE_TILE") || getenv("MTV_FORCE_LDS") || getenv("MTV_FORCE_LIN");     // (not MTV_FORCE_WIN:
+                                                                                                                                                           //  k_conv_win serves the large levels)
 }
 void force_lds_tile(const ConvArgs& a, ConvTile* t) {
     if (g_force_lin[0] == -1) {
@@ -1008,6 +1010,14 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
         }
     }
     if (g_force_lin[0] > 0 && conv_lin_eligible(a)) { *t = ConvTile{g_force_lin[0], g_force_lin[1], 64, g_force_lin[2], 0}; return; }
+    if (g_force_win[0] == -1) {
+        g_force_win[0] = 0;
+        if (const char* e = getenv("MTV_FORCE_WIN")) {
+            int x = 0, y = 0;
+            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 1 || x == 2) && (y == 2 || y == 4)) { g_force_win[0] = x; g_force_win[1] = y; }
+        }
+    }
+    if (g_force_win[0] > 0 && conv_win_eligible(a, g_force_win[0], g_force_win[1])) { *t = ConvTile{g_force_win[0], g_force_win[1], 80, 1, 0}; return; }
     parse_force_b3();
     if (g_force_b3[0] > 0 && conv_x3_eligible(a) && conv_x3_smem_bytes(a, ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0}) <= CONV_X3_MAX_LDS) {
         const int nch32 = a.ntaps * (a.Cmain / 32) + a.Cskip / 32;
@@ -1114,7 +1124,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     p->tuned = true;
     tune_cache_load(c);
     const char* env = getenv("MTV_AUTOTUNE");
-    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0 || g_force_lin[0] > 0 || g_force_b3[0] > 0) return MTV_OK;
+    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0 || g_force_lin[0] > 0 || g_force_b3[0] > 0 || g_force_win[0] > 0) return MTV_OK;
     static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
     struct Events {             // destroyed on every exit path (HIPCHK returns early)
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1153,12 +1163,13 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
             const bool b3_ok = t.NW == 48 && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
-            const bool shape_ok = tiled_ok || lin_ok || b3_ok ||
+            const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && t.XM == 0 && conv_win_eligible(a, t.MT, t.NT);
+            const bool shape_ok = tiled_ok || lin_ok || b3_ok || win_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
                                    t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1));
-            if (!shape_ok || (!tiled_ok && !lin_ok && !b3_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
-                (!b3_ok && conv_smem_bytes(a, t) > 120 * 1024)) {
+            if (!shape_ok || (!tiled_ok && !lin_ok && !b3_ok && !win_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
+                (!b3_ok && !win_ok && conv_smem_bytes(a, t) > 120 * 1024)) {
                 c->tune_cache.erase(it);
                 it = c->tune_cache.end();
             }
@@ -1265,6 +1276,30 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                             best = t;
                         }
                     }
+            }
+            // the window-staged 3x3 kernel (deep.hip, k_conv_win): GroupNorm / FiLM / SiLU once per element, all taps from LDS
+            if (a.ntaps == 9 && (long)a.B * a.Lout >= 256) {
+                static const int tw[][2] = {{1, 4}, {1, 2}, {2, 2}};
+                for (auto& mn : tw) {
+                    if (!conv_win_eligible(a, mn[0], mn[1])) continue;
+                    const ConvTile t{mn[0], mn[1], 80, 1, 0};
+                    if ((long)a.B * ((a.Lout + 16 * t.MT - 1) / (16 * t.MT)) * (a.N / (16 * t.NT)) < 64) continue;
+                    float samp[16];
+                    HIPCHK(launch_conv(a, t, s));
+                    for (int w = 0; w < nsamp; ++w) {
+                        HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
+                        HIPCHK(hipEventRecord(e0, s));
+                        HIPCHK(launch_conv(a, t, s));
+                        HIPCHK(hipEventRecord(e1, s));
+                        HIPCHK(hipEventSynchronize(e1));
+                        HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
+                    }
+                    std::sort(samp, samp + nsamp);
+                    if (samp[nsamp / 2] < best_ms) {
+                        best_ms = samp[nsamp / 2];
+                        best = t;
+                    }
+                }
             }
             // the lean 1x1 kernel (lin.hip): wave tile 16 MT x 16 NT, NWV waves side by side along N, whole K per wave
             if (conv_lin_eligible(a)) {
@@ -1950,6 +1985,13 @@ int mtv_debug_force_lin(int mt, int nt, int nwv) {
     if (mt == 0) { g_force_lin[0] = 0; return MTV_OK; }
     if (!((mt == 1 || mt == 2) && (nt == 1 || nt == 2 || nt == 4) && (nwv == 1 || nwv == 2 || nwv == 4))) return fail(MTV_ERR_INVALID, "k_lin tile must be {1,2} x {1,2,4} x {1,2,4}");
     g_force_lin[0] = mt; g_force_lin[1] = nt; g_force_lin[2] = nwv;
+    return MTV_OK;
+}
+
+int mtv_debug_force_win(int mt, int nt) {
+    if (mt == 0) { g_force_win[0] = 0; return MTV_OK; }
+    if (!((mt == 1 && (nt == 2 || nt == 4)) || (mt == 2 && nt == 2))) return fail(MTV_ERR_INVALID, "k_conv_win tile must be 1x2, 1x4 or 2x2");
+    g_force_win[0] = mt; g_force_win[1] = nt;
     return MTV_OK;
 }
 

@@ -563,3 +563,32 @@ def test_deep_kernels_against_cpu_conv_and_attention():
     for mode, ok in (("check", "CHECK OK"), ("attn", "ATTN CHECK OK")):
         out = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and ok in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
+
+
+@pytest.mark.parametrize("mt,nt", [(1, 4), (1, 2), (2, 2)])
+def test_window_staged_conv_kernel_vs_reference_golden(mt, nt):
+    """k_conv_win (csrc/deep.hip: the transformed input window of a row tile staged in LDS once, all nine taps read from it) forced
+    onto every eligible 3x3 conv: eps of the base UNet vs the reference golden, the narrow / shallow models' taps (two clips), and a
+    ragged two-clip geometry (row tiles that straddle planes, windows clipped by plane borders) vs the oracle."""
+    from moditalker_amd import _lib
+    from oracle import ref_unet
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_force_win(mt, nt), "mtv_debug_force_win")
+    try:
+        g = np.load(os.path.join(GOLDEN, "base.npz"))
+        net = _build(BASE_CFG, 7, max_batch=1)
+        dev = _dev()
+        x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+        for tv in (999, 0):
+            eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
+            assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
+        names = [p["name"] for p in net.diffusion_model.profile_forward(1, 1, dev)]
+        assert sum(",80,1]" in n for n in names) >= 20, "the window-staged kernel was not selected"
+        cfg = dict(BASE_CFG, image_size=24)            # 24x24 | 8x24 | 8x24 planes: ragged tiles at every level
+        net2 = _build(cfg, 21, frames=8, max_batch=2)
+        x, cond, ic = filler.synthetic_inputs(2, 24, 8, seed=5, tag="win")
+        t = torch.tensor([700, 3])
+        ref = ref_unet.unet_forward({k: v.cpu() for k, v in net2.state_dict().items()}, cfg, x, cond, ic, t, 24, 8)
+        assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
+    finally:
+        lib.mtv_debug_force_win(0, 0)
