@@ -138,7 +138,9 @@ int mtv_profile_step(mtv_ctx* ctx, int batch, int iters, mtv_op_time* out, int c
  * with plain launches; the in-kernel phase timestamps of four sampled workgroups per conv are written to `path`. */
 int mtv_debug_stamps(mtv_ctx* ctx, int batch, const char* path, void* stream);
 
-/* Testing aid: plans built after this call run every eligible convolution on the LDS-tiled kernel k_conv_lds<wm, wn>
+/* (All mtv_debug_force_* knobs: set them BEFORE a context builds its first plan of a batch size -- plans of one batch size share their
+ * split-K slab and split-activation scratch, sized for the tiles in force when the first of them is built.)
+ * Testing aid: plans built after this call run every eligible convolution on the LDS-tiled kernel k_conv_lds<wm, wn>
  * (wave tile 16 wm x 16 wn, workgroup 2 x 2 waves) instead of the tuned choice; wm = 0 switches it off again. */
 int mtv_debug_force_lds(int wm, int wn);
 /* Testing aid: plans built after this call run every eligible convolution / GEMM (any row count) on the split-bf16 kernels

@@ -714,7 +714,7 @@ bool conv_x3_eligible(const ConvArgs& a) {
     for (int k = 0; k < 4; ++k)
         if (a.C[k] & 7) return false;
     for (int t = 0; t < a.nstat; ++t)
-        if (a.stat[t].gs & 3) return false;
+        if ((a.stat[t].gs & 3) || (a.stat[t].coff & 3)) return false;      // (the statistics epilogue assigns whole 4-column quads to a group)
     return true;
 }
 

@@ -1047,7 +1047,7 @@ int finish_split_k(mtv_ctx* c, Plan* plan) {
         const size_t one = (size_t)B * op->a.Lout * op->a.N;
         size_t ks = 16;
         while (ks > 1 && ks * one * 4 > ((size_t)64 << 20)) ks /= 2;
-        if ((size_t)op->t.KS > ks) ks = op->t.KS;
+        if (op->t.NW != 64 && op->t.NW != 80 && (size_t)op->t.KS > ks) ks = op->t.KS;      // (k_lin's KS is a wave count, k_conv_win never splits K)
         if (ks < 2) continue;                       // never split: needs no slab (the autoencoder's 16384-token GEMMs)
         need = ks * one > need ? ks * one : need;
     }
@@ -1149,20 +1149,30 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
         char key[176];
         snprintf(key, sizeof key, "B%d L%d/%d/%d N%d t%d C%d+%d gn%d f%d r%d s%d cm%d", a.B, a.Lout, a.Lsrc, a.Lskip, a.N, a.ntaps, a.Cmain, a.Cskip,
                  a.gn.sums ? 1 : 0, a.gn.film ? 1 : 0, a.res ? 1 : 0, a.nstat, a.out_cm);
-        auto it = c->tune_cache.find(key);
-        // Two 1x1 convs can share a key and differ in whether the lean kernel (k_lin: identity rows, [N][K] weight copy) can run them.
-        // The entry of the one it can run must not be evicted (and re-timed in every process) by the other: that one has its own
-        // entry under "<key> x".
-        if (it != c->tune_cache.end() && it->second.NW == 64 && !conv_lin_eligible(a)) {
-            strncat(key, " x", sizeof key - strlen(key) - 1);
+        // Two 1x1 convs can share a shape key and differ in whether the lean kernel (k_lin: identity rows, [N][K] weight copy) can run
+        // them.  Whatever order they are met in, each has its own entry: "<key> l" for the one k_lin can run (falling back to a plain
+        // "<key>" of an older table), the plain key for the other -- unless that holds a k_lin tile, then "<key> x".
+        const bool lin_ok_conv = conv_lin_eligible(a);
+        auto it = c->tune_cache.end();
+        if (lin_ok_conv) {
+            char kl[192];
+            snprintf(kl, sizeof kl, "%s l", key);
+            it = c->tune_cache.find(kl);
+            if (it == c->tune_cache.end()) it = c->tune_cache.find(key);
+            if (it == c->tune_cache.end()) strncpy(key, kl, sizeof key - 1);      // a new measurement goes under the "l" key
+        } else {
             it = c->tune_cache.find(key);
+            if (it != c->tune_cache.end() && it->second.NW == 64) {
+                strncat(key, " x", sizeof key - strlen(key) - 1);
+                it = c->tune_cache.find(key);
+            }
         }
         if (it != c->tune_cache.end()) {             // an entry read from MTV_TUNE_CACHE is only trusted if it is launchable
             const ConvTile& t = it->second;
             const int nchunks = a.ntaps * (a.Cmain / 16) + a.Cskip / 16;
             const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
-            const bool b3_ok = t.NW == 48 && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
+            const bool b3_ok = t.NW == 48 && !(a.B == 1 && a.Lout <= 2048) && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
             const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && t.XM == 0 && conv_win_eligible(a, t.MT, t.NT);
             const bool shape_ok = tiled_ok || lin_ok || b3_ok || win_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
@@ -1248,7 +1258,8 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                 }
             }
             // the split-bf16 kernels (conv_x3.hip) for large token counts: the timed launch is the elementwise pass + the GEMM
-            if ((long)a.B * a.Lout >= X3_MIN_ROWS && conv_x3_eligible(a) && a.x3) {
+            // (not for the one-clip step at R = 32, the metric's workload: it stays on the exact-f32 instruction throughout)
+            if ((long)a.B * a.Lout >= X3_MIN_ROWS && !(a.B == 1 && a.Lout <= 2048) && conv_x3_eligible(a) && a.x3) {
                 static const int tb[][2] = {{4, 2}, {2, 2}, {4, 1}, {2, 1}, {8, 2}, {8, 1}, {4, 4}};
                 const int nch32 = a.ntaps * (a.Cmain / 32) + a.Cskip / 32;
                 for (auto& mn : tb)

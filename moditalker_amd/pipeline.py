@@ -141,7 +141,11 @@ def make_video(result_frames, audio_path: Optional[str], save_path: str, fps: in
         import imageio
     except ImportError as e:
         raise RuntimeError("make_video needs imageio (+ imageio-ffmpeg), as MToV/sample.py does; PNG frames and GIFs need only PIL") from e
-    silent = save_path.replace(".mp4", "no_audio.mp4") if audio_path else save_path
+    if audio_path and not save_path.endswith(".mp4"):
+        # (the reference forms the silent name with .replace('.mp4', ...): without that suffix ffmpeg would read and write the SAME
+        # file and the final os.remove would delete the result)
+        raise ValueError("make_video: save_path must end in .mp4 when an audio track is muxed in (sample.py:107-116)")
+    silent = os.path.splitext(save_path)[0] + "no_audio.mp4" if audio_path else save_path
     imageio.mimwrite(silent, list(result_frames), fps=fps, output_params=["-vf", f"fps={fps}"])
     if audio_path:
         if shutil.which("ffmpeg") is None:
