@@ -17,13 +17,24 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt 
 KT=$(find $O/kt -name '*kernel_trace.csv' | head -1)
 cp "$(find $O/kt -name '*kernel_stats.csv' | head -1)" $O/r${NN}_rocprofv3_kernel_stats.csv
 python tools/per_op_rocprof.py $O/r${NN}_per_launch_hipevents.txt $KT $O/r${NN}_per_op_rocprof.txt > /dev/null 2>&1
-# 5. PMC passes, each in its own run, kernel trace only (never combined with hip/hsa/sys trace domains).  MTV_EAGER=1: the
-#    same launches as plain launches -- rocprofv3 --pmc segfaults at the first hipGraph replay of the round-2 step graph
-for c in FETCH_SIZE WRITE_SIZE; do
-    MTV_EAGER=1 timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- \
-        python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_$c.log 2>&1
-    echo "pmc $c rc=$?"
-done
+# 5. PMC passes, each in its own run, kernel trace only (never combined with hip/hsa/sys trace domains), on the MEASURED path: the
+#    hipGraph replay (round 2's image segfaulted there; round 3 found it working again).  A pass that fails or leaves no counter
+#    file is repeated with MTV_EAGER=1 (the same launches as plain launches) and the summary says which one it was.
+pmc_pass() {   # $1 = output dir tag, rest = counters
+    local tag=$1; shift
+    timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$tag -o p -- \
+        python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_$tag.log 2>&1
+    local rc=$?
+    if [ $rc -ne 0 ] || [ -z "$(find $O/pmc_$tag -name '*counter_collection.csv' | head -1)" ]; then
+        echo "pmc $tag on the graph path: rc=$rc -> eager"; rm -rf $O/pmc_$tag
+        MTV_EAGER=1 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$tag -o p -- \
+            python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_$tag.log 2>&1
+        echo "$tag eager" >> $O/pmc_modes.txt
+    else
+        echo "$tag graph" >> $O/pmc_modes.txt
+    fi
+}
+for c in FETCH_SIZE WRITE_SIZE; do pmc_pass $c $c; done
 PF=$(find $O/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 PW=$(find $O/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 NL=$(grep -m1 -oE '^# [0-9]+ launches' $O/r${NN}_per_launch_hipevents.txt | grep -oE '[0-9]+')
@@ -31,22 +42,18 @@ python tools/summarize_profile.py $KT --launches $NL ${PF:+--fetch $PF} ${PW:+--
 python tools/per_op_traffic.py $O/r${NN}_per_launch_hipevents.txt $PF $PW --out $O/r${NN}_per_op_traffic.txt > /dev/null 2>&1
 # 5b. matrix-pipe / VALU utilisation counters (one more PMC pass, SQ + GRBM blocks only) -> MFMA utilisation per kernel family,
 #     and the counter-based GB/s of the conv family (north_star: "rocprof counters reporting achieved HBM GB/s ... and MFMA utilisation")
-MTV_EAGER=1 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE \
-    --output-format csv -d $O/pmc_SQ -o p -- python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_SQ.log 2>&1
-echo "pmc SQ rc=$?"
+pmc_pass SQ SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE
+echo "pmc passes: $(tr '\n' ' ' < $O/pmc_modes.txt)"
 PS=$(find $O/pmc_SQ -name '*counter_collection.csv' | head -1)
 python tools/pmc_util.py $PS --launches $NL --fetch $PF --write $PW --trace $KT --json $O/pmc_util.json > $O/r${NN}_pmc_util.txt 2>&1
 python tools/update_pmc_traffic.py $O/pmc_util.json "round $NN (tools/make_profiles.sh)" "$(git rev-parse --short HEAD 2>/dev/null)"; cp profiles/pmc_traffic.json $O/pmc_traffic.json
 # 3. the bench line (N=1, with cpu_baseline and batched_info), quoting the counters just collected
 timeout 500 python bench.py --steps 250 --warmup 25 > $O/r${NN}_bench_n1.json 2>$O/bench.err
-# 5c. does --pmc survive a hipGraph replay on this image?  (round 2: segfault at the first replay.)  One short try, graph mode.
-timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_graph -o p -- \
-    python bench.py --steps 10 --warmup 2 --ramp-steps 5 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_graph.log 2>&1
-echo "pmc on the graph path: rc=$? ($(find $O/pmc_graph -name '*counter_collection.csv' | wc -l) counter files)" | tee -a $O/r${NN}_pmc_util.txt
-rm -rf $O/pmc_SQ $O/pmc_graph
+rm -rf $O/pmc_SQ
 # 6. configs[3] (R=64), informational
 timeout 300 python bench.py --res 64 --steps 40 --warmup 10 --no-cpu-baseline --batched-clips 0 > /dev/null 2>&1
-timeout 300 python bench.py --res 64 --steps 150 --warmup 15 --no-cpu-baseline --batched-clips 0 > $O/r${NN}_bench_res64_n1.json 2>/dev/null
+# (with the CPU leg: BASELINE.md section 3 asks for >= 3 timed steps of the oracle at this geometry; bench.py stops it after 60 s)
+timeout 600 python bench.py --res 64 --steps 150 --warmup 15 --batched-clips 0 > $O/r${NN}_bench_res64_n1.json 2>/dev/null
 # 7. the autoencoder steps either side of the loop (informational): per-launch tables + rocprofv3 kernel stats of decode
 timeout 300 python tools/ae_profile.py > $O/r${NN}_ae_decode_per_launch.txt 2>/dev/null
 timeout 300 python tools/ae_profile.py --extract > $O/r${NN}_ae_extract_per_launch.txt 2>/dev/null
@@ -60,5 +67,15 @@ sed '/^# attention/,$d' $O/stamps_all.txt > $O/r${NN}_conv_phase_stamps.txt
 # 9. micro-benchmarks: the launch chain, f32 MFMA vs VALU on one SIMD
 timeout 120 tools/ubench/chain > $O/r${NN}_launch_chain_ubench.txt 2>&1
 timeout 120 tools/ubench/mfma_valu > $O/r${NN}_mfma_valu_ubench.txt 2>&1
+# 10. the kernels of the deep levels on their own (tools/ubench/deep_bench): correctness against plain CPU restatements, the chain
+#     experiment (40 dependent convs with distinct weights vs the same chain on k_conv; 16 ops = weights that fit the Infinity Cache),
+#     the fused attention + proj_out kernel; the -DMTV_DEEP_STAMP build adds the in-kernel phase anatomy
+timeout 300 tools/ubench/deep_bench check > $O/r${NN}_deep_check.txt 2>&1
+timeout 300 tools/ubench/deep_bench attn >> $O/r${NN}_deep_check.txt 2>&1
+if [ -x tools/ubench/deep_bench_stamp ]; then DB=tools/ubench/deep_bench_stamp; else DB=tools/ubench/deep_bench; fi
+(for cfg in "40 4 2" "40 8 4" "16 4 2" "16 8 4"; do timeout 120 $DB chain $cfg 2>&1 | grep -v "final act"; done) > $O/r${NN}_deep_chain.txt
+timeout 120 $DB attn time 2>&1 | grep -v "^ATTN" > $O/r${NN}_deep_attn.txt
+# 11. one page of numbers, written by a script from the files above (no hand-typed figures)
+python tools/round_summary.py $NN $O > $O/r${NN}_summary.md 2>$O/summary.err
 rm -rf $O/kt $O/ktae $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 tail -25 $O/r${NN}_step_summary.txt

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""One page of numbers for profiles/rNN_summary.md, written from the files tools/make_profiles.sh has just produced (no hand-typed
+figures): the bench line, the per-family kernel times of the rocprofv3 trace, the counter-derived figures.
+Usage: round_summary.py NN <dir with rNN_* files>"""
+import json
+import os
+import re
+import sys
+
+nn, d = sys.argv[1], sys.argv[2]
+
+
+def rd(name):
+    p = os.path.join(d, name)
+    return open(p).read() if os.path.exists(p) else ""
+
+
+def jline(name):
+    for l in reversed(rd(name).splitlines()):
+        if l.startswith("{"):
+            return json.loads(l)
+    return None
+
+
+b = jline(f"r{nn}_bench_n1.json")
+print(f"# Round {nn}: numbers of `tools/make_profiles.sh {nn}` (one MI355X, one process; written by tools/round_summary.py)\n")
+if b:
+    r, c = b["roofline"], b.get("cpu_baseline") or {}
+    print("| | |\n|---|---|")
+    print(f"| `value` (N = 1, {b['steps']} timed steps) | **{b['value']} denoise-steps/s, {b['ms_per_step']} ms per step**, {b['launches_per_step']} launches per step |")
+    print(f"| `roofline` ({r['kernel']}) | {r['achieved']} TFLOP/s = **{r['frac']}** of the f32-MFMA peak; {r['launches_per_step']} launches, {r['avg_launch_us']} us average; "
+          f"counter-side {r.get('hbm_counter_GBs')} GB/s, matrix pipe busy {r.get('mfma_util_counter')} |")
+    ra = b.get("roofline_attention") or {}
+    print(f"| `roofline_attention` (k_attention) | {ra.get('achieved')} TFLOP/s = **{ra.get('frac')}**; {ra.get('launches_per_step')} launches; matrix pipe busy {ra.get('mfma_util_counter')} |")
+    for k, v in (b.get("families") or {}).items():
+        print(f"| family `{k}` | {v['ms_per_step']} ms per step, {v['launches']} launches" + (f", {v['tflops']} TFLOP/s" if v.get("tflops") else "") +
+              (f", {v['algorithmic_GBs']} GB/s algorithmic" if v.get("algorithmic_GBs") else "") + " |")
+    if c:
+        ph = c.get("physical_cores_rule") or {}
+        print(f"| `cpu_baseline` | {c['value']} steps/s at {c['cores']} threads ({c['sample'][:80]}...); physical-core rule: {ph.get('value')} steps/s at {ph.get('threads')} threads ({ph.get('steps')} steps) |")
+    print(f"| `gpu_active_s` | {b.get('gpu_active_s')} |")
+    bi, ai = b.get("batched_info"), b.get("autoencoder_info")
+    if bi:
+        print(f"| 8 clips batched (informational) | {bi['clip_steps_per_s']} clip-steps/s, conv {bi['k_conv_frac_of_f32_mfma_peak']} / attention {bi['k_attention_frac_of_f32_mfma_peak']} of the f32-MFMA peak |")
+    if ai:
+        print(f"| autoencoder (informational) | decode {ai['decode_from_sample_ms']} ms, extract {ai['extract_ms']} ms, GEMMs {ai.get('gemm_frac_of_f32_mfma_peak')} of peak; clip end to end {ai['clip_end_to_end_ms_at_250_steps']} ms |")
+b64 = jline(f"r{nn}_bench_res64_n1.json")
+if b64:
+    c = b64.get("cpu_baseline") or {}
+    print(f"| configs[3] (R = 64) | {b64['value']} steps/s, {b64['ms_per_step']} ms per step; CPU oracle {c.get('value')} steps/s at {c.get('cores')} threads ({(c.get('sample') or '')[:40]}...) |")
+print()
+po = rd(f"r{nn}_per_op_rocprof.txt")
+if po:
+    print("## Kernel time per family (rocprofv3 kernel trace of the hipGraph replay, median per launch)\n\n```")
+    print("\n".join(l for l in po.splitlines() if l.startswith("#")))
+    print("```\n")
+ss = rd(f"r{nn}_step_summary.txt")
+if ss:
+    print("## Per-step kernel view and the PMC bytes of the same passes\n\n```")
+    print("\n".join(ss.splitlines()[:40]))
+    print("```\n")
+pu = rd(f"r{nn}_pmc_util.txt")
+if pu:
+    print("## Counter-derived utilisation (tools/pmc_util.py; PMC passes: " + " ".join(rd("pmc_modes.txt").split()) + ")\n\n```")
+    print(pu.strip())
+    print("```\n")
+dc = rd(f"r{nn}_deep_chain.txt")
+if dc:
+    print("## Deep-level kernels on their own (tools/ubench/deep_bench)\n\n```")
+    print("\n".join(l for l in dc.splitlines() if not l.lstrip().startswith("stamps")))
+    print("```")
