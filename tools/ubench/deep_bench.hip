@@ -323,7 +323,7 @@ static void do_chain(int nops, int r, int t, int ks_arg, int nrg_arg) {
         unsigned long long h[64];
         CK(hipMemcpy(h, da[nops / 2].dbg, sizeof h, hipMemcpyDeviceToHost));
         static const char* nm[16] = {"entry", "decoded", "stats added", "barrier 1", "transformed+barrier", "mfma done", "barrier", "end", "tables built", "main staged", "skip staged", "-", "slabs issued", "weights issued", "barrier 0", "first group done"};
-        static const int order[2][16] = {{1, 12, 13, 8, 14, 9, 10, 2, 3, 4, 15, 5, 6, 7, -1}, {1, 12, 13, 8, 14, 9, 10, 2, 3, 4, 15, 5, 6, 7, -1}};
+        static const int order[2][16] = {{1, 12, 13, 8, 14, 9, 10, 2, 3, 4, 5, 6, 7, -1}, {1, 12, 13, 8, 14, 9, 10, 2, 3, 4, 5, 6, 7, -1}};
         for (int blk = 0; blk < 2; ++blk)
             for (int role = 0; role < 2; ++role) {
                 printf("  stamps op %d wg %s %s (cycles since entry):", nops / 2, blk ? "mid" : "0", role ? "wave 4" : "wave 0");
