@@ -336,6 +336,18 @@ struct AeBuilder {
         const double bytes = 4.0 * ((double)K * N + N) + 4.0 * a.B * ((double)rows * K + (double)rows * N * (res ? 2 : 1));
         char tag[64];
         snprintf(tag, sizeof tag, "[%dx%d k%d]", a.B * rows, N, K);
+        if (geglu_h) {       // the tuner times each candidate as the plan would run it: fused pair, or k_geglu + the GEMM
+            float* gl = const_cast<float*>(in);
+            const long ntok_all = (long)a.B * rows;
+            op->tune_launch = [geglu_h, gl, ntok_all, K](const ConvArgs& ta, ConvTile tt, hipStream_t s) -> hipError_t {
+                ConvOp probe;
+                probe.a = ta;
+                probe.t = tt;
+                if (x3_fused_geglu(probe)) return launch_conv_x3_geglu(ta, tt, geglu_h, s);
+                hipError_t e = launch_geglu(geglu_h, gl, ntok_all, K, 0, s);
+                return e != hipSuccess ? e : launch_conv(ta, tt, s);
+            };
+        }
         if (geglu_h)
             push(op->base_name + tag, [op, geglu_h](hipStream_t s) { return x3_fused_geglu(*op) ? launch_conv_x3_geglu(op->a, op->t, geglu_h, s) : launch_conv(op->a, op->t, s); }, flops, bytes);
         else

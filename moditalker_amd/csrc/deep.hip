@@ -1011,21 +1011,41 @@ template <int MT, int NT>
 __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     touch_kernargs<(int)sizeof(ConvArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ROWS = 16 * MT, COLS = 16 * NT, G = 3;
+    constexpr int ROWS = 16 * MT, COLS = 16 * NT;
+    constexpr int G = MT * NT <= 2 ? 5 : 3;                // weight chunks per register set (two sets: 2 G chunks of look-ahead per wave)
     constexpr int MAXR = 12;                               // window rows in flight per thread (first pass)
+    static_assert(MAXR >= 2 * G, "the first 2 G weight chunks are requested between the rows of the first pass");
     typedef float bvec __attribute__((ext_vector_type(NT)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = deep_usgpr(tid >> 6);
     const int i = lane & 15, q = lane >> 4;
     // block -> (column tile, clip, row tile): column tiles of one row tile are 1 / tiles_n of the grid apart, so with a multiple of 8
     // row tiles they share an XCD (and the window they all stage)
+    // xmap 1 / 2 (ConvTile::XM = 1; weight-dominated shapes): workgroup id mod 8 = the XCD selects the column tile, so a weight column
+    // tile is fetched by ONE L2 (tiles_n a multiple of 8: Sx column tiles per XCD) or by 8 / tiles_n of them (tiles_n = 2^Sx < 8) and
+    // the (smaller) activation windows are what the XCDs re-read.  Speed only.
+    DEEP_STAMP(0);
     const int blk = deep_usgpr((int)blockIdx.x);
-    const int ct = deep_usgpr(FDiv{a.inv_Bt}(blk, a.Bt));
-    const int brt = blk - ct * a.Bt;
+    int ct, brt;
+    if (a.xmap == 0) {
+        ct = FDiv{a.inv_Bt}(blk, a.Bt);
+        brt = blk - ct * a.Bt;
+    } else if (a.xmap == 1) {
+        const int xcd = blk & 7, j = blk >> 3;
+        brt = FDiv{a.inv_Sx}(j, a.Sx);
+        ct = xcd + 8 * (j - brt * a.Sx);
+    } else {
+        const int xcd = blk & 7, j = blk >> 3;
+        ct = xcd & ((1 << a.Sx) - 1);
+        brt = (j << (3 - a.Sx)) + (xcd >> a.Sx);
+    }
+    ct = deep_usgpr(ct);
+    brt = deep_usgpr(brt);
     const int b = deep_usgpr(FDiv{a.inv_tiles_per_b}(brt, a.tiles_per_b));
     const int tok0 = (brt - b * a.tiles_per_b) * ROWS, n0 = ct * COLS;
     const int Cmain = a.Cmain, Cskip = a.Cskip;
     const int SW = Cmain + DEEP_PAD, SK = Cskip + DEEP_PAD;
+    DEEP_STAMP(1);
     const int wcap = a.rec_cap;                            // window capacity in rows (host); row wcap of the window = zeros
     float* const lwin = smem;                              // [wcap + 1][SW]
     float* const lraw = lwin + (wcap + 1) * SW;            // [ROWS + 1][SK]: raw rows of the fused 1x1 skip conv
@@ -1067,13 +1087,20 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
             xr[u] = *reinterpret_cast<const f32x4*>(xcol + (size_t)(row < wn ? row : 0) * xstride);
         }
     }
-    f32x4 sraw = {0.f, 0.f, 0.f, 0.f};
+    constexpr int SRN = 4;                                 // raw skip quads in flight per thread (first pass: 16 MT rows x up to 512 / MT channels)
+    f32x4 sraw[SRN];
     const int QS = Cskip >> 2, C2 = a.C[2];
-    const bool has_sraw = Cskip && tid < ROWS * QS && tok0 + tid / (QS > 0 ? QS : 1) < a.Lout;
-    if (has_sraw) {
-        const int row = tid / QS, c = 4 * (tid - row * QS);
-        const float* p = c < C2 ? a.src[2] + ((size_t)b * a.Lskip + tok0 + row) * C2 + c : a.src[3] + ((size_t)b * a.Lskip + tok0 + row) * a.C[3] + (c - C2);
-        sraw = *reinterpret_cast<const f32x4*>(p);
+    auto skip_ptr = [&](int e) {
+        const int row = e / QS, c = 4 * (e - row * QS);
+        return c < C2 ? a.src[2] + ((size_t)b * a.Lskip + tok0 + row) * C2 + c : a.src[3] + ((size_t)b * a.Lskip + tok0 + row) * a.C[3] + (c - C2);
+    };
+    if (Cskip) {
+#pragma unroll
+        for (int u = 0; u < SRN; ++u) {
+            const int e = tid + u * DEEP_NTH;
+            if (u * DEEP_NTH < ROWS * QS)                          // (uniform)
+                sraw[u] = *reinterpret_cast<const f32x4*>(skip_ptr(e < ROWS * QS && tok0 + e / QS < a.Lout ? e : 0));
+        }
     }
     const int cpt = a.cpt, nmain_ch = 9 * cpt, nch = nmain_ch + (Cskip >> 4);
     const int n_it = (nch + 7) >> 3;
@@ -1081,10 +1108,9 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, wrows * a.ldw * 4, 0x00020000);
     const int wlane = ((4 * q) * a.ldw + n0 + NT * i) * 4;
     bvec bq[2][G][4];
-    auto wload = [&](bvec (&dst)[G][4], int k0) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int c = wave + 8 * (k0 + g);
+    auto wload1 = [&](bvec (&dstg)[4], int kc) {
+        {
+            const int c = wave + 8 * kc;
             // W row of the chunk's first channel: tap-major over the concatenated main channels, then the skip channels (k_conv's
             // order of rows); a chunk past the end reads out of range = zeros
             int krow = 9 * Cmain + (c - nmain_ch) * 16;
@@ -1092,13 +1118,23 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
             const int soff = c < nch ? krow * a.ldw * 4 : 0x7F000000;
 #pragma unroll
             for (int sI = 0; sI < 4; ++sI) {
-                if constexpr (NT == 4) dst[g][sI] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + sI * a.ldw * 4, soff, 0));
-                else dst[g][sI] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, wlane + sI * a.ldw * 4, soff, 0));
+                if constexpr (NT == 4) dstg[sI] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + sI * a.ldw * 4, soff, 0));
+                else dstg[sI] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, wlane + sI * a.ldw * 4, soff, 0));
             }
         }
     };
-    wload(bq[0], 0);
-    wload(bq[1], G);
+    auto wload = [&](bvec (&dst)[G][4], int k0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) wload1(dst[g], k0 + g);
+    };
+#ifndef MTV_WIN_WORDER
+#define MTV_WIN_WORDER 0
+#endif
+    // MTV_WIN_WORDER (experiment): 0 = weights requested between the rows of the transform, 1 = all 2 G chunks here, 2 = G here, G below
+    constexpr int W_EARLY = MTV_WIN_WORDER == 1 ? 2 * G : (MTV_WIN_WORDER == 2 ? G : 0);
+#pragma unroll
+    for (int u = 0; u < W_EARLY; ++u) wload1(bq[u / G][u % G], u);
+    DEEP_STAMP(2);
     // ---- while they fly: row table (LDS float offsets: window row of every (tap, output row), the zero row for padding), zero rows
     for (int e = tid; e < 9 * ROWS; e += DEEP_NTH) {
         const int tap = e / ROWS, ri = e - tap * ROWS;
@@ -1119,30 +1155,38 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         f64x2 v0 = vraw[0];
 #pragma unroll
         for (int k = 1; k < STAT_COPIES; ++k) v0 += vraw[k];
-        sdp[2 * tid] = v0[0];
-        sdp[2 * tid + 1] = v0[1];
+        if (a.gn.whole) {
+            sdp[2 * tid] = v0[0];
+            sdp[2 * tid + 1] = v0[1];
+        } else {                                                   // per-plane statistics: (mean, rstd) of this (plane, group) right here
+            const int sg = tid >> 5;
+            const double n0 = a.gn.inv_n[0], n1 = a.gn.inv_n[1], n2 = a.gn.inv_n[2];     // (scalar loads; an indexed read becomes a vector load + vmcnt(0))
+            const double inv_n = sg == 0 ? n0 : (sg == 1 ? n1 : n2);
+            const double mean = v0[0] * inv_n;
+            double var = v0[1] * inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_mr[tid] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
+        }
     }
     __syncthreads();
-    if (do_gn && tid < 96) {
-        const int sg = tid >> 5, g = tid & 31;
-        double sx, sy, inv_n;
-        if (a.gn.whole) {
-            sx = (sdp[2 * g] + sdp[2 * (32 + g)]) + sdp[2 * (64 + g)];
-            sy = (sdp[2 * g + 1] + sdp[2 * (32 + g) + 1]) + sdp[2 * (64 + g) + 1];
-            inv_n = a.gn.inv_n[3];
-        } else {
-            sx = sdp[2 * tid];
-            sy = sdp[2 * tid + 1];
-            inv_n = a.gn.inv_n[sg];
+    DEEP_STAMP(3);
+    if (do_gn && a.gn.whole) {                                     // whole-L statistics (not a resblock conv): the three planes added up
+        if (tid < 96) {
+            const int g = tid & 31;
+            const double sx = (sdp[2 * g] + sdp[2 * (32 + g)]) + sdp[2 * (64 + g)];
+            const double sy = (sdp[2 * g + 1] + sdp[2 * (32 + g) + 1]) + sdp[2 * (64 + g) + 1];
+            const double inv_n = a.gn.inv_n[3];
+            const double mean = sx * inv_n;
+            double var = sy * inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_mr[tid] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
         }
-        const double mean = sx * inv_n;
-        double var = sy * inv_n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        s_mr[tid] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
+        __syncthreads();
     }
-    if (do_gn) __syncthreads();
+    DEEP_STAMP(4);
     // ---- transform this thread's window rows ONCE (y = x A + B, SiLU) and park them; then the raw skip rows
-    if (stager) {
+    DEEP_STAMP(4);
+    {
         const bool act = a.gn.act != 0;
         const SegInfo ss = a.seg_src;
         int cur = -1;
@@ -1173,27 +1217,33 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         };
 #pragma unroll
         for (int u = 0; u < MAXR; ++u) {
-            if (u * RP >= wn) break;
-            const int row = rl + u * RP;
-            if (row < wn) transform(row, xr[u]);
-        }
-        for (int row = rl + MAXR * RP; row < wn; row += RP)       // (windows taller than MAXR RP rows: requested late, behind the weights)
-            transform(row, *reinterpret_cast<const f32x4*>(xcol + (size_t)row * xstride));
-    }
-    if (has_sraw) {
-        const int row = tid / QS, c = 4 * (tid - row * QS);
-        *reinterpret_cast<f32x4*>(lraw + row * SK + c) = sraw;
-    }
-    if (Cskip)
-        for (int e = tid + DEEP_NTH; e < ROWS * QS; e += DEEP_NTH) {
-            const int row = e / QS, c = 4 * (e - row * QS);
-            if (tok0 + row < a.Lout) {
-                const float* p = c < C2 ? a.src[2] + ((size_t)b * a.Lskip + tok0 + row) * C2 + c : a.src[3] + ((size_t)b * a.Lskip + tok0 + row) * a.C[3] + (c - C2);
-                *reinterpret_cast<f32x4*>(lraw + row * SK + c) = *reinterpret_cast<const f32x4*>(p);
+            if (u + W_EARLY < 2 * G) wload1(bq[(u + W_EARLY) / G][(u + W_EARLY) % G], u + W_EARLY);       // (every thread; chunk indices past the end read as zeros)
+            if (stager && u * RP < wn) {                          // (uniform but for the stager test)
+                const int row = rl + u * RP;
+                if (row < wn) transform(row, xr[u]);
             }
         }
+        if (stager)
+            for (int row = rl + MAXR * RP; row < wn; row += RP)   // (windows taller than MAXR RP rows: requested late, behind the weights)
+                transform(row, *reinterpret_cast<const f32x4*>(xcol + (size_t)row * xstride));
+    }
+    if (Cskip) {
+#pragma unroll
+        for (int u = 0; u < SRN; ++u) {
+            const int e = tid + u * DEEP_NTH;
+            if (u * DEEP_NTH < ROWS * QS && e < ROWS * QS) {
+                const int row = e / QS, c = 4 * (e - row * QS);
+                if (tok0 + row < a.Lout) *reinterpret_cast<f32x4*>(lraw + row * SK + c) = sraw[u];
+            }
+        }
+        for (int e = tid + SRN * DEEP_NTH; e < ROWS * QS; e += DEEP_NTH) {       // (wider skips: requested late, behind the weights)
+            const int row = e / QS, c = 4 * (e - row * QS);
+            if (tok0 + row < a.Lout) *reinterpret_cast<f32x4*>(lraw + row * SK + c) = *reinterpret_cast<const f32x4*>(skip_ptr(e));
+        }
+    }
     __syncthreads();
     // ---- K loop: A fragments from the window (one chunk ahead), weights of iteration k + 2G replace those of k
+    DEEP_STAMP(5);
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1242,6 +1292,23 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         for (int g = 0; g < G; ++g)
             if (G + g < rem) step(k + G + g, (G + g) & 1, bq[1][g]);
     }
+    DEEP_STAMP(6);
+    // ---- epilogue operands of this thread's output quad, requested before the partial tiles are exchanged (a round trip off the tail)
+    constexpr int QPR = COLS / 4;
+    static_assert(ROWS * QPR <= DEEP_NTH, "one output quad per thread");
+    const int e_rr = tid / QPR, e_cq = tid - e_rr * QPR;
+    const int e_tok = tok0 + e_rr, e_n = n0 + 4 * e_cq;
+    const bool e_on = tid < ROWS * QPR && e_tok < a.Lout;
+    f32x4 e_add = {0.f, 0.f, 0.f, 0.f}, e_b2 = e_add, e_bb = e_add, e_res = e_add;
+    if (e_on) {
+        e_add = *reinterpret_cast<const f32x4*>(a.bias + e_n);
+        if (a.bias2) e_b2 = *reinterpret_cast<const f32x4*>(a.bias2 + e_n);
+        if (a.bias_b) e_bb = *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + e_n);
+        if (a.res) {
+            const int rs = a.geo_skip ? (geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, e_tok, 1, 1, true) & 0x0FFFFFFF) : e_tok;
+            e_res = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + rs) * a.N + e_n);
+        }
+    }
     __syncthreads();
     // ---- the eight partial tiles -> (row, col) images (lane (i, q) holds, for row 4q + r, the NT consecutive columns NT i ..)
     constexpr int LDR = COLS + 4;
@@ -1259,6 +1326,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
             }
     }
     __syncthreads();
+    DEEP_STAMP(7);
     // ---- epilogue: bias / per-clip bias / residual, coalesced store, statistics of the output for its consumers
     float* scratch = red + 8 * ROWS * LDR;                   // statistics slots (deep_stat_one layout: 4 floats, then [2][96][2] doubles)
     {
@@ -1266,31 +1334,25 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         for (int e = tid; e < a.nstat * 96 * 2; e += DEEP_NTH) st[e] = 0.0;
         if (a.nstat) __syncthreads();
     }
-    constexpr int QPR = COLS / 4;
-    for (int e = tid; e < ROWS * QPR; e += DEEP_NTH) {
-        const int rr = e / QPR, cq = e - rr * QPR;
-        const int tok = tok0 + rr, n = n0 + 4 * cq;
-        if (tok >= a.Lout) continue;
-        const float* rp = red + rr * LDR + 4 * cq;
+    if (e_on) {                                               // (same order of additions as before: partials in wave order, bias, bias2, per-clip bias, residual)
+        const float* rp = red + e_rr * LDR + 4 * e_cq;
         f32x4 v = *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
         for (int w = 1; w < 8; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
-        v += *reinterpret_cast<const f32x4*>(a.bias + n);
-        if (a.bias2) v += *reinterpret_cast<const f32x4*>(a.bias2 + n);
-        if (a.bias_b) v += *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + n);
-        if (a.res) {
-            const int rs = a.geo_skip ? (geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
-            v += *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + rs) * a.N + n);
-        }
-        *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
-        if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, tok, n, v);
-        if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, tok, n, v);
+        v += e_add;
+        if (a.bias2) v += e_b2;
+        if (a.bias_b) v += e_bb;
+        if (a.res) v += e_res;
+        *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + e_tok) * a.N + e_n) = v;
+        if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, e_tok, e_n, v);
+        if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, e_tok, e_n, v);
     }
     if (a.nstat) {
         __syncthreads();
         deep_stat_flush_one(a.stat[0], 0, a.stat_cstride, scratch, b, tid);
         if (a.nstat > 1) deep_stat_flush_one(a.stat[1], 1, a.stat_cstride, scratch, b, tid);
     }
+    DEEP_STAMP(9);
 }
 
 // =====================================================================================
@@ -1542,7 +1604,7 @@ hipError_t launch_deep_attn(const DeepAttnArgs& a0, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ---- k_conv_win (ConvTile{MT, NT, NW = 80, KS = 1, XM = 0}) ----
+// ---- k_conv_win (ConvTile{MT, NT, NW = 80, KS = 1, XM}) ----
 static size_t conv_win_layout(const ConvArgs& a, int MT, int NT, int* wcap_out) {
     const int ROWS = 16 * MT, COLS = 16 * NT;
     int wcap = 1;                                           // the tallest window of any row tile (same arithmetic as the kernel)
@@ -1573,12 +1635,23 @@ bool conv_win_eligible(const ConvArgs& a, int MT, int NT) {
 size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_win_layout(a, t.MT, t.NT, nullptr); }
 
 template <int MT, int NT>
-static hipError_t conv_win_launch_t(const ConvArgs& a0, hipStream_t s) {
+static hipError_t conv_win_launch_t(const ConvArgs& a0, int xm, hipStream_t s) {
     ConvArgs a = a0;
     if (!conv_win_eligible(a, MT, NT)) return hipErrorInvalidValue;
     const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT), tiles_n = a.N / (16 * NT);
     a.KS = 1;
     a.xmap = 0;
+    if (xm) {                                               // (a grid the XCD map does not tile keeps the plain order)
+        const long nblk = (long)a.B * tiles * tiles_n;
+        if (tiles_n % 8 == 0) {
+            a.xmap = 1;
+            a.Sx = tiles_n / 8;
+            a.inv_Sx = 1.0f / (float)a.Sx;
+        } else if ((tiles_n == 1 || tiles_n == 2 || tiles_n == 4) && nblk % 8 == 0) {
+            a.xmap = 2;
+            a.Sx = tiles_n == 1 ? 0 : (tiles_n == 2 ? 1 : 2);
+        }
+    }
     a.tiles_per_b = tiles;
     a.tiles_n = tiles_n;
     a.Bt = a.B * tiles;
@@ -1595,9 +1668,11 @@ static hipError_t conv_win_launch_t(const ConvArgs& a0, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s) {
-    if (t.MT == 1 && t.NT == 4) return conv_win_launch_t<1, 4>(a, s);
-    if (t.MT == 1 && t.NT == 2) return conv_win_launch_t<1, 2>(a, s);
-    if (t.MT == 2 && t.NT == 2) return conv_win_launch_t<2, 2>(a, s);
+    static const int env_xm = getenv("MTV_WIN_XM") ? atoi(getenv("MTV_WIN_XM")) : -1;       // (A/B hook: block order of every k_conv_win launch)
+    if (env_xm >= 0) t.XM = env_xm;
+    if (t.MT == 1 && t.NT == 4) return conv_win_launch_t<1, 4>(a, t.XM, s);
+    if (t.MT == 1 && t.NT == 2) return conv_win_launch_t<1, 2>(a, t.XM, s);
+    if (t.MT == 2 && t.NT == 2) return conv_win_launch_t<2, 2>(a, t.XM, s);
     return hipErrorInvalidValue;
 }
 

@@ -1017,7 +1017,11 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
             if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 1 || x == 2) && (y == 2 || y == 4)) { g_force_win[0] = x; g_force_win[1] = y; }
         }
     }
-    if (g_force_win[0] > 0 && conv_win_eligible(a, g_force_win[0], g_force_win[1])) { *t = ConvTile{g_force_win[0], g_force_win[1], 80, 1, 0}; return; }
+    if (g_force_win[0] > 0 && conv_win_eligible(a, g_force_win[0], g_force_win[1])) {
+        static const int xm = getenv("MTV_FORCE_WIN_XM") ? atoi(getenv("MTV_FORCE_WIN_XM")) != 0 : 0;      // (with the XCD-aware block order)
+        *t = ConvTile{g_force_win[0], g_force_win[1], 80, 1, xm};
+        return;
+    }
     parse_force_b3();
     if (g_force_b3[0] > 0 && conv_x3_eligible(a) && conv_x3_smem_bytes(a, ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0}) <= CONV_X3_MAX_LDS) {
         const int nch32 = a.ntaps * (a.Cmain / 32) + a.Cskip / 32;
@@ -1146,6 +1150,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     for (auto& op : p->convs) {
         ConvArgs a = op->a;
         a.ddim = nullptr;       // the tuner times the conv itself, not the step hand-over
+        auto run = [&](const ConvTile& tt) -> hipError_t { return op->tune_launch ? op->tune_launch(a, tt, s) : launch_conv(a, tt, s); };
         char key[176];
         snprintf(key, sizeof key, "B%d L%d/%d/%d N%d t%d C%d+%d gn%d f%d r%d s%d cm%d", a.B, a.Lout, a.Lsrc, a.Lskip, a.N, a.ntaps, a.Cmain, a.Cskip,
                  a.gn.sums ? 1 : 0, a.gn.film ? 1 : 0, a.res ? 1 : 0, a.nstat, a.out_cm);
@@ -1173,7 +1178,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
             const bool b3_ok = t.NW == 48 && !(a.B == 1 && a.Lout <= 2048) && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
-            const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && t.XM == 0 && conv_win_eligible(a, t.MT, t.NT);
+            const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && (t.XM == 0 || t.XM == 1) && conv_win_eligible(a, t.MT, t.NT);
             const bool shape_ok = tiled_ok || lin_ok || b3_ok || win_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
@@ -1211,11 +1216,11 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                             // (median of `nsamp` samples: a single slow sample -- clock ramp, a neighbour's
                             // traffic -- must not decide the plan)
                             float samp[16];
-                            HIPCHK(launch_conv(a, t, s));
+                            HIPCHK(run(t));
                             for (int w = 0; w < nsamp; ++w) {
                                 HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
                                 HIPCHK(hipEventRecord(e0, s));
-                                HIPCHK(launch_conv(a, t, s));
+                                HIPCHK(run(t));
                                 HIPCHK(hipEventRecord(e1, s));
                                 HIPCHK(hipEventSynchronize(e1));
                                 HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
@@ -1241,11 +1246,11 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                     if ((long)a.B * ((a.Lout + 32 * t.MT - 1) / (32 * t.MT)) * ((a.N + 32 * t.NT - 1) / (32 * t.NT)) < 128) continue;
                     if (conv_smem_bytes(a, t) > 120 * 1024) continue;
                     float samp[16];
-                    HIPCHK(launch_conv(a, t, s));
+                    HIPCHK(run(t));
                     for (int w = 0; w < nsamp; ++w) {
                         HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
                         HIPCHK(hipEventRecord(e0, s));
-                        HIPCHK(launch_conv(a, t, s));
+                        HIPCHK(run(t));
                         HIPCHK(hipEventRecord(e1, s));
                         HIPCHK(hipEventSynchronize(e1));
                         HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
@@ -1272,11 +1277,11 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                         if (KS > 1 && (ntile * (KS / 2) >= 256 || nch32 / KS < 6 || (size_t)KS * a.B * a.Lout * a.N > slab_cap)) continue;
                         if (conv_x3_smem_bytes(a, t) > CONV_X3_MAX_LDS) continue;
                         float samp[16];
-                        HIPCHK(launch_conv(a, t, s));
+                        HIPCHK(run(t));
                         for (int w = 0; w < nsamp; ++w) {
                             HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
                             HIPCHK(hipEventRecord(e0, s));
-                            HIPCHK(launch_conv(a, t, s));
+                            HIPCHK(run(t));
                             HIPCHK(hipEventRecord(e1, s));
                             HIPCHK(hipEventSynchronize(e1));
                             HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
@@ -1291,16 +1296,19 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             // the window-staged 3x3 kernel (deep.hip, k_conv_win): GroupNorm / FiLM / SiLU once per element, all taps from LDS
             if (a.ntaps == 9 && (long)a.B * a.Lout >= 256) {
                 static const int tw[][2] = {{1, 4}, {1, 2}, {2, 2}};
+                // block order by rule, not by timing (it moves L2 misses, not time: profiles/r04_conv_win_xcd_order.txt): one XCD per
+                // weight column tile where the weights are the larger operand
+                const int XM = wbytes >= abytes ? 1 : 0;
                 for (auto& mn : tw) {
                     if (!conv_win_eligible(a, mn[0], mn[1])) continue;
-                    const ConvTile t{mn[0], mn[1], 80, 1, 0};
+                    const ConvTile t{mn[0], mn[1], 80, 1, XM};
                     if ((long)a.B * ((a.Lout + 16 * t.MT - 1) / (16 * t.MT)) * (a.N / (16 * t.NT)) < 64) continue;
                     float samp[16];
-                    HIPCHK(launch_conv(a, t, s));
+                    HIPCHK(run(t));
                     for (int w = 0; w < nsamp; ++w) {
                         HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
                         HIPCHK(hipEventRecord(e0, s));
-                        HIPCHK(launch_conv(a, t, s));
+                        HIPCHK(run(t));
                         HIPCHK(hipEventRecord(e1, s));
                         HIPCHK(hipEventSynchronize(e1));
                         HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
@@ -1321,11 +1329,11 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                             if (16 * NT * NWV > a.N && NWV > 1) continue;           // wider than the layer
                             const ConvTile t{MT, NT, 64, NWV, 0};
                             float samp[16];
-                            HIPCHK(launch_conv(a, t, s));
+                            HIPCHK(run(t));
                             for (int w = 0; w < nsamp; ++w) {
                                 HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
                                 HIPCHK(hipEventRecord(e0, s));
-                                HIPCHK(launch_conv(a, t, s));
+                                HIPCHK(run(t));
                                 HIPCHK(hipEventRecord(e1, s));
                                 HIPCHK(hipEventSynchronize(e1));
                                 HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));

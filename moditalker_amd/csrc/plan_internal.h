@@ -89,6 +89,9 @@ struct ConvOp {                 // one convolution of the plan; args/tile are pa
     ConvTile t;
     std::string base_name;
     int op_index = -1;
+    // set when the launch the plan really issues for a tile is not launch_conv(a, t) alone (the autoencoder's ff2 GEMM: GEGLU folded into
+    // the split pass on the split-bf16 pair, a separate k_geglu launch otherwise): the tuner times THIS
+    std::function<hipError_t(const ConvArgs&, ConvTile, hipStream_t)> tune_launch;
 };
 
 struct DeepOp {                 // one K-sliced conv of the deep levels (deep.hip)

@@ -455,12 +455,115 @@ static int do_attn(bool timing) {
     return bad;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- k_conv_win
+// chain of dependent 3x3 convs of a LARGE level ([L x C] -> [L x C], GroupNorm + SiLU in the prologue, statistics by the epilogue),
+// distinct weights per op: k_conv tiles against the k_conv_win tiles, us per op inside one hipGraph; stamps of the win kernel
+static void do_win(int nops, int r, int t, int C) {
+    const int N = C, K = 9 * C, ldw = (C + 63) / 64 * 64, b1 = r * r, b2 = b1 + t * r, L = b2 + t * r;
+    printf("win: chain of %d dependent 3x3 convs [%d x %d, K = %d] (r %d t %d), weights %.2f MB each\n", nops, L, N, K, r, t, K * N * 4e-6);
+    std::vector<float> W((size_t)K * ldw), ones(C, 1.0f), zeros(C, 0.f), x((size_t)L * C);
+    const float wsc = 1.0f / sqrtf((float)K);
+    for (auto& v : x) v = frand();
+    float *gamma = dup(ones), *beta = dup(zeros), *bias = dup(zeros);
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    CK(conv_init_attrs());
+    CK(deep_init_attrs());
+    std::vector<int> g((size_t)9 * L, -1);
+    for (int tok = 0; tok < L; ++tok)
+        for (int tap = 0; tap < 9; ++tap) { const int gg = geo_source(r, t, tok, tap / 3, tap % 3, false); g[(size_t)tap * L + tok] = gg < 0 ? -1 : (gg & 0x0FFFFFFF); }
+    int* dg = dnew<int>(g.size());
+    CK(hipMemcpy(dg, g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float*> dW(nops);
+    for (int o = 0; o < nops; ++o) {
+        for (auto& v : W) v = frand() * wsc;
+        dW[o] = dup(W);
+    }
+    float* actA[2] = {dup(x), dnew<float>((size_t)L * C)};
+    double* sites = dnew<double>((size_t)(nops + 1) * STAT_COPIES * 192);
+    const unsigned cstride = (unsigned)((nops + 1) * 192);
+    float* slab = dnew<float>((size_t)16 * L * N);
+    int* tickets = dnew<int>(1 << 16);
+    unsigned long long* dbg = dnew<unsigned long long>(64);
+    std::vector<ConvArgs> ca(nops);
+    for (int o = 0; o < nops; ++o) {
+        ConvArgs a{};
+        a.src[0] = actA[o & 1]; a.C[0] = C; a.nmain = 1; a.Cmain = C; a.gather = dg; a.ntaps = 9; a.Lout = L; a.Lsrc = L; a.Lskip = L; a.B = 1;
+        a.W = dW[o]; a.ldw = ldw; a.N = N; a.bias = bias; a.out = actA[(o + 1) & 1];
+        a.seg_src = SegInfo{b1, b2, L}; a.seg_out = a.seg_src; a.slab = slab; a.tickets = tickets;
+        a.geo_main = 1; a.geo_r = r; a.geo_t = t;
+        a.gn = GnIn{sites + (size_t)o * 192, gamma, beta, nullptr, 0, C / 32, 0, 1, cstride};
+        a.gn.inv_gs = 1.0f / (C / 32);
+        a.gn.inv_n[0] = 1.0 / ((double)b1 * (C / 32)); a.gn.inv_n[1] = 1.0 / ((double)(b2 - b1) * (C / 32)); a.gn.inv_n[2] = 1.0 / ((double)(L - b2) * (C / 32)); a.gn.inv_n[3] = 1.0 / ((double)L * (C / 32));
+        a.stat[0] = StatOut{sites + (size_t)(o + 1) * 192, C / 32, 0, 1.0f / (C / 32)};
+        a.nstat = 1; a.stat_cstride = cstride;
+        if (o == nops / 2) a.dbg = dbg;
+        ca[o] = a;
+    }
+    {
+        std::vector<double> hs(192, 0.0);
+        for (int tok = 0; tok < L; ++tok)
+            for (int ch = 0; ch < C; ++ch) { const int p = tok >= b2 ? 2 : (tok >= b1 ? 1 : 0); const double v = x[(size_t)tok * C + ch]; hs[(p * 32 + ch / (C / 32)) * 2] += v; hs[(p * 32 + ch / (C / 32)) * 2 + 1] += v * v; }
+        CK(hipMemcpy(sites, hs.data(), 192 * 8, hipMemcpyHostToDevice));
+    }
+    std::vector<float> ref;
+    auto run_tile = [&](ConvTile tile) {
+        if (tile.NW == 80 && !conv_win_eligible(ca[0], tile.MT, tile.NT)) return;
+        if (tile.NW != 80 && conv_smem_bytes(ca[0], tile) > 120 * 1024) return;
+        CK(hipMemcpy(actA[0], x.data(), x.size() * 4, hipMemcpyHostToDevice));
+        hipGraph_t gr; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        CK(hipMemsetAsync(sites + 192, 0, (size_t)((nops + 1) * STAT_COPIES * 192 - 192) * 8, s));
+        for (int o = 0; o < nops; ++o) CK(launch_conv(ca[o], tile, s));
+        CK(hipStreamEndCapture(s, &gr));
+        CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        std::vector<float> got((size_t)L * C);
+        CK(hipMemcpy(got.data(), actA[nops & 1], got.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0;
+        if (ref.empty()) ref = got;
+        else for (size_t e = 0; e < got.size(); ++e) worst = std::max(worst, (double)fabsf(got[e] - ref[e]));
+        for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, s));
+        const int reps = 30;
+        for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, s));
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  tile %d,%d,%d,%d,%d  %7.2f us per op   (max|diff| to the first tile after %d ops %.2e)\n", tile.MT, tile.NT, tile.NW, tile.KS, tile.XM, ms * 1e3 / reps / nops, nops, worst);
+#ifdef MTV_DEEP_STAMP
+        if (tile.NW == 80) {
+            unsigned long long h[64];
+            CK(hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
+            static const char* nm[10] = {"entry", "decoded", "requests issued", "tables+barrier", "stats barrier", "window parked", "mfma done", "partials parked", "-", "end"};
+            static const int order[] = {1, 2, 3, 4, 5, 6, 7, 9, -1};
+            for (int blk = 0; blk < 2; ++blk)
+                for (int role = 0; role < 2; ++role) {
+                    printf("    stamps wg %s %s:", blk ? "mid" : "0", role ? "wave 4" : "wave 0");
+                    for (int k = 0; order[k] >= 0; ++k) printf("  %s %lld", nm[order[k]], (long long)(h[blk * 32 + role * 16 + order[k]] - h[blk * 32 + role * 16]));
+                    printf("\n");
+                }
+        }
+#endif
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(gr));
+    };
+    const ConvTile tiles[] = {{1, 4, 8, 1, 0}, {2, 4, 8, 1, 0}, {2, 2, 8, 1, 0}, {2, 4, 4, 1, 0}, {1, 2, 8, 1, 0}, {1, 4, 80, 1, 0}, {1, 2, 80, 1, 0}, {2, 2, 80, 1, 0}, {1, 2, 80, 1, 1}, {2, 2, 80, 1, 1}};
+    for (const ConvTile& tl : tiles) run_tile(tl);
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && !strcmp(argv[1], "check")) { CK(deep_init_attrs()); return do_check(); }
     if (argc >= 2 && !strcmp(argv[1], "chain")) {
         const int nops = argc >= 3 ? atoi(argv[2]) : 40;
         const int r = argc >= 5 ? atoi(argv[3]) : 4, t = argc >= 5 ? atoi(argv[4]) : 2;
         do_chain(nops, r, t, argc >= 6 ? atoi(argv[5]) : 0, argc >= 7 ? atoi(argv[6]) : 0);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "win")) {
+        do_win(argc >= 3 ? atoi(argv[2]) : 20, argc >= 5 ? atoi(argv[3]) : 32, argc >= 5 ? atoi(argv[4]) : 16, argc >= 6 ? atoi(argv[5]) : 128);
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "attn")) { CK(deep_init_attrs()); return do_attn(argc >= 3); }
