@@ -1269,6 +1269,10 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
 #pragma unroll
                     for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][sI], w[sI][nb], acc[mt][nb], 0, 0, 0);
         };
+        // (measured and dropped, profiles/r04_conv_win_stamps.txt: a two-step-deep A pipeline pinned with sched_barrier, 13.2 -> 14.3 us per
+        // op on [2048 x 128] -- the barrier also keeps the next chunk's address arithmetic out of the MFMA block; the three planes'
+        // coefficient sets hoisted out of the row loop, 13.2 -> 13.6: as an array they go to scratch, as named registers they cost more
+        // than the 4 LDS reads per row they save)
         f32x4 avA[MT], avB[MT];
         auto step = [&](int kk, int par, const bvec (&w)[4]) {
             if (par) { loadA(kk + 1, avA); mma(avB, w); }
