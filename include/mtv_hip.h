@@ -155,6 +155,10 @@ int mtv_debug_force_lin(int mt, int nt, int nwv);
  * the window-staged kernel k_conv_win<mt, nt> (row tile 16 mt x column tile 16 nt; the transformed input rows of the tile and their
  * halo staged in LDS once, csrc/deep.hip) instead of the tuned choice; mt = 0 switches it off again. */
 int mtv_debug_force_win(int mt, int nt);
+/* Testing aid: plans built after this call run every eligible 1x1 convolution on identity rows (the attention blocks' qkv / proj_out,
+ * unet.py:234,253) on k_conv_pw<mt, ntw> (16 mt rows normalised once into LDS, 8 waves side by side along 128 ntw output channels, ntw = 1 | 2,
+ * whole K per wave; csrc/deep.hip) instead of the tuned choice; mt = 0 switches it off again. */
+int mtv_debug_force_pw(int mt, int ntw);
 /* Which attention core the UNet's self-attention launches take (head dim 16 / 32 / 64; process-wide, takes effect at the
  * next launch / graph capture): 0 = the exact-f32 core k_attention everywhere (the default: it is the faster one on
  * MI355X at every shape measured), 1 = the split-bf16 core k_attention_b3 (csrc/attn_b3.hip) on every eligible launch,

@@ -1225,6 +1225,7 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
 
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
     if (t.NW == 80) return conv_win_smem_bytes(a, t);
+    if (t.NW == 96) return conv_pw_smem_bytes(a, t);
     if (t.NW == 64) return lin_smem_bytes(a);
     if (t.NW == 48) return conv_x3_smem_bytes(a, t);
     if (t.NW == 32) return lds_bytes_tiled(t.MT, t.NT, a.ntaps, a.Cmain, a.Cskip, a.gn.sums != nullptr);
@@ -1325,6 +1326,13 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
         if (conv_win_eligible(a, t.MT, t.NT)) return launch_conv_win(a, t, s);
         t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);   // (statistics targets are
         t.KS = 1;                                                                                                       // attached after the op is created)
+        a.KS = 1;
+        a.xmap = t.XM;
+    }
+    if (t.NW == 96) {            // 1x1 kernel of the large levels (deep.hip: k_conv_pw)
+        if (conv_pw_eligible(a, t.MT, t.NT)) return launch_conv_pw(a, t, s);
+        t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);
+        t.KS = 1;
         a.KS = 1;
         a.xmap = t.XM;
     }

@@ -1360,6 +1360,259 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
 }
 
 // =====================================================================================
+// k_conv_pw: 1x1 conv on identity rows at the LARGE levels (qkv / proj_out of the attention blocks at 512 / 2048 tokens)
+// =====================================================================================
+// Same arguments, results layout and statistics hand-over as k_conv (ConvArgs).  k_conv runs a 1x1 conv as a one-tap convolution with
+// K = 128 .. 512 split over its 8 waves (one or two 16-channel chunks each, then an 8-wave reduction); k_lin gave every wave the whole K
+// but re-derived the GroupNorm coefficients and re-transformed the rows per wave.  Here the 16 MT rows of a workgroup are normalised ONCE
+// into LDS (k_conv_win's prologue: statistics -> (mean, rstd) through one barrier, per-thread coefficients of one channel quad), the 8
+// waves sit side by side along N (16 NTW columns each, whole K, no reduction), weights come in the checkpoint's own [N][K] layout
+// (ConvArgs::Wnk: lane (j, q) loads W[n][c0 + 4q .. + 3], one 16-byte request per 16-channel chunk and column block), requested
+// between the rows of the transform, and the accumulators go through LDS once so that stores, residual reads and statistics are
+// 16-byte wide.  Workgroup = (clip, row tile, group of 128 NTW columns), 512 threads.
+template <int MT, int NTW>
+__global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
+    touch_kernargs<(int)sizeof(ConvArgs)>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, COLS = 128 * NTW;
+    constexpr int G = NTW == 1 ? 8 : 4;                    // weight chunks per register set (two sets: K = 256 is in flight whole at NTW = 1)
+    constexpr int MAXR = 8;                                // rows in flight per thread
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = deep_usgpr(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    DEEP_STAMP(0);
+    const int blk = deep_usgpr((int)blockIdx.x);
+    const int cg = deep_usgpr(FDiv{a.inv_Bt}(blk, a.Bt));
+    const int brt = blk - cg * a.Bt;
+    const int b = deep_usgpr(FDiv{a.inv_tiles_per_b}(brt, a.tiles_per_b));
+    const int tok0 = (brt - b * a.tiles_per_b) * ROWS, n0 = cg * COLS;
+    const int K = a.Cmain, SA = K + DEEP_PAD;
+    float* const lA = smem;                                // [ROWS][SA]
+    double* const sdp = reinterpret_cast<double*>(lA + ROWS * SA);      // [96][2] whole-L statistics only
+    float2* const s_mr = reinterpret_cast<float2*>(sdp + 192);         // [3][32] (mean, rstd)
+    const bool do_gn = a.gn.sums != nullptr;
+    DEEP_STAMP(1);
+    // ---- requests, oldest first = needed first: input statistics, GroupNorm vectors of this thread's channel quad, its rows (raw)
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 vraw[STAT_COPIES];
+    if (do_gn && tid < 96) {
+#pragma unroll
+        for (int k = 0; k < STAT_COPIES; ++k) vraw[k] = *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)tid * 2);
+    }
+    const int QW = K >> 2, RP = DEEP_NTH / QW;             // staging map: thread -> quad column qd of rows rl, rl + RP, ...
+    const int qd = tid % QW, rl = tid / QW;
+    const bool stager = rl < RP;
+    const int c4 = 4 * qd;
+    const float* film = (do_gn && a.gn.film) ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = ga, f1 = ga, f2 = ga;
+    if (do_gn && stager) {
+        ga = *reinterpret_cast<const f32x4*>(a.gn.gamma + c4);
+        be = *reinterpret_cast<const f32x4*>(a.gn.beta + c4);
+        f1 = *reinterpret_cast<const f32x4*>((film ? film : a.gn.gamma) + c4);
+        f2 = *reinterpret_cast<const f32x4*>((film ? film + K : a.gn.beta) + c4);
+    }
+    const int nrows = a.Lout - tok0 < ROWS ? a.Lout - tok0 : ROWS;
+    const float* xcol = a.src[0] + ((size_t)b * a.Lsrc + tok0) * K + c4;
+    f32x4 xr[MAXR];
+    if (stager) {
+#pragma unroll
+        for (int u = 0; u < MAXR; ++u)
+            if (u * RP < ROWS) {                                       // (uniform)
+                const int row = rl + u * RP;
+                xr[u] = *reinterpret_cast<const f32x4*>(xcol + (size_t)(row < nrows ? row : 0) * K);
+            }
+    }
+    // weights: wave w owns the NTW column blocks of 16 that start at n0 + 16 NTW w; lane (j, q) holds, of column block nb, output
+    // channel nw0 + NTW j + nb (its NTW channels are consecutive: 4 NTW-float runs per lane in the LDS image below)
+    const int nw0 = n0 + 16 * NTW * wave;
+    const bool wave_on = nw0 < a.N;                        // (N is a multiple of 16 NTW: a wave is all in or all out)
+    const int nch = K >> 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wnk), 0, a.N * K * 4, 0x00020000);
+    const int wlane = ((nw0 + NTW * i) * K + 4 * q) * 4;
+    f32x4 bq[2][G][NTW];
+    auto wload1 = [&](f32x4 (&dstg)[NTW], int c) {
+        const int soff = (c < nch && wave_on) ? c * 64 : 0x7F000000;      // (past the end: out of range = zeros)
+#pragma unroll
+        for (int nb = 0; nb < NTW; ++nb) dstg[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + nb * K * 4, soff, 0));
+    };
+    auto wload = [&](f32x4 (&dst)[G][NTW], int c0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) wload1(dst[g], c0 + g);
+    };
+    DEEP_STAMP(2);
+    if (do_gn && tid < 96) {
+        f64x2 v0 = vraw[0];
+#pragma unroll
+        for (int k = 1; k < STAT_COPIES; ++k) v0 += vraw[k];
+        if (a.gn.whole) {
+            sdp[2 * tid] = v0[0];
+            sdp[2 * tid + 1] = v0[1];
+        } else {
+            const int sg = tid >> 5;
+            const double i0 = a.gn.inv_n[0], i1 = a.gn.inv_n[1], i2 = a.gn.inv_n[2];
+            const double inv_n = sg == 0 ? i0 : (sg == 1 ? i1 : i2);
+            const double mean = v0[0] * inv_n;
+            double var = v0[1] * inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_mr[tid] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
+        }
+    }
+    if (do_gn) __syncthreads();
+    DEEP_STAMP(3);
+    if (do_gn && a.gn.whole) {
+        if (tid < 96) {
+            const int g = tid & 31;
+            const double sx = (sdp[2 * g] + sdp[2 * (32 + g)]) + sdp[2 * (64 + g)];
+            const double sy = (sdp[2 * g + 1] + sdp[2 * (32 + g) + 1]) + sdp[2 * (64 + g) + 1];
+            const double inv_n = a.gn.inv_n[3];
+            const double mean = sx * inv_n;
+            double var = sy * inv_n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            s_mr[tid] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
+        }
+        __syncthreads();
+    }
+    DEEP_STAMP(4);
+    // ---- transform this thread's rows ONCE (y = x A + B, SiLU where the norm has one) and park them; weights go out in between
+    {
+        const bool act = a.gn.act != 0;
+        const SegInfo ss = a.seg_src;
+        int cur = -1;
+        f32x4 A = {1.f, 1.f, 1.f, 1.f}, Bc = {0.f, 0.f, 0.f, 0.f};
+        auto transform = [&](int row, f32x4 y) {
+            if (do_gn) {
+                const int tk = tok0 + row;
+                const int sg = tk >= ss.b2 ? 2 : (tk >= ss.b1 ? 1 : 0);
+                if (sg != cur) {
+                    cur = sg;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float2 mr = s_mr[sg * 32 + FDiv{a.gn.inv_gs}(c4 + k, a.gn.gs)];
+                        const float sc = mr.y * ga[k];
+                        const float bi = be[k] - sc * mr.x;
+                        const float s1 = film ? 1.0f + f1[k] : 1.0f, sh = film ? f2[k] : 0.f;
+                        A[k] = sc * s1;
+                        Bc[k] = fmaf(bi, s1, sh);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = fmaf(y[k], A[k], Bc[k]);
+                    y[k] = act ? deep_silu(t) : t;
+                }
+            }
+            *reinterpret_cast<f32x4*>(lA + row * SA + c4) = y;
+        };
+#pragma unroll
+        for (int u = 0; u < (2 * G > MAXR ? 2 * G : MAXR); ++u) {
+            if (u < 2 * G) wload1(bq[u / G][u % G], u);            // (every thread; chunks past K read as zeros without traffic)
+            if (u < MAXR && stager && u * RP < ROWS) {
+                const int row = rl + u * RP;
+                if (row < ROWS) {
+                    if (row < nrows) transform(row, xr[u]);
+                    else *reinterpret_cast<f32x4*>(lA + row * SA + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (stager)
+            for (int row = rl + MAXR * RP; row < ROWS; row += RP) {        // (K = 512 with 32 rows: requested late)
+                if (row < nrows) transform(row, *reinterpret_cast<const f32x4*>(xcol + (size_t)row * K));
+                else *reinterpret_cast<f32x4*>(lA + row * SA + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    // epilogue operands of this thread's first output quad: requested before the K loop's barrier (a round trip off the tail)
+    constexpr int QPR = COLS / 4, NQ = ROWS * QPR, EPT = (NQ + DEEP_NTH - 1) / DEEP_NTH;
+    f32x4 e_res[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        e_res[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int e = tid + u * DEEP_NTH;
+        const int rr = e / QPR, cq = e - rr * QPR;
+        if (a.res && e < NQ && tok0 + rr < a.Lout && n0 + 4 * cq < a.N)
+            e_res[u] = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + tok0 + rr) * a.N + n0 + 4 * cq);
+    }
+    __syncthreads();
+    DEEP_STAMP(5);
+    // ---- K loop: a wave multiplies the whole K for its 16 NTW columns; A fragments from the parked rows
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < NTW; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave_on) {
+        const float* ab = lA + i * SA + 4 * q;
+        auto step = [&](int c, const f32x4 (&w)[NTW]) {
+            f32x4 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(ab + 16 * mt * SA + c * 16);
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nb = 0; nb < NTW; ++nb) acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][sI], w[nb][sI], acc[mt][nb], 0, 0, 0);
+        };
+        int c = 0;
+        for (; c + 2 * G <= nch; c += 2 * G) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) step(c + g, bq[0][g]);
+            if (c + 2 * G < nch) wload(bq[0], c + 2 * G);          // (uniform; K = 128 is one pass: nothing more to request)
+#pragma unroll
+            for (int g = 0; g < G; ++g) step(c + G + g, bq[1][g]);
+            if (c + 3 * G < nch) wload(bq[1], c + 3 * G);
+        }
+        const int rem = nch - c;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (g < rem) step(c + g, bq[0][g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (G + g < rem) step(c + G + g, bq[1][g]);
+    }
+    DEEP_STAMP(6);
+    __syncthreads();                                               // (the parked rows are dead: their LDS becomes the output image)
+    // ---- accumulators -> [ROWS][COLS + 4] image: lane (i, q) holds, for row 4q + r of row tile mt, channels NTW i .. NTW i + NTW - 1 of its wave
+    constexpr int LDR = COLS + 4;
+    float* const red = smem;
+    if (wave_on) {
+        float* my = red + (4 * q) * LDR + 16 * NTW * wave + NTW * i;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int nb = 0; nb < NTW; ++nb) my[(16 * mt + rr) * LDR + nb] = acc[mt][nb][rr];
+    }
+    float* scratch = red + ROWS * LDR;
+    {
+        double* st = reinterpret_cast<double*>(scratch + 4);
+        for (int e = tid; e < a.nstat * 96 * 2; e += DEEP_NTH) st[e] = 0.0;
+    }
+    __syncthreads();
+    DEEP_STAMP(7);
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int e = tid + u * DEEP_NTH;
+        const int rr = e / QPR, cq = e - rr * QPR;
+        const int tok = tok0 + rr, n = n0 + 4 * cq;
+        if (e < NQ && tok < a.Lout && n < a.N) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(red + rr * LDR + 4 * cq);
+            v += *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.res) v += e_res[u];
+            *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
+            if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, tok, n, v);
+            if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, tok, n, v);
+        }
+    }
+    if (a.nstat) {
+        __syncthreads();
+        deep_stat_flush_one(a.stat[0], 0, a.stat_cstride, scratch, b, tid);
+        if (a.nstat > 1) deep_stat_flush_one(a.stat[1], 1, a.stat_cstride, scratch, b, tid);
+    }
+    DEEP_STAMP(9);
+}
+
+// =====================================================================================
 // host side
 // =====================================================================================
 size_t deep_weight_floats(const DeepArgs& a, int NT) {
@@ -1539,7 +1792,9 @@ hipError_t deep_init_attrs() {
     }
     const void* fa[] = {reinterpret_cast<const void*>(&k_deep_attn<16>), reinterpret_cast<const void*>(&k_deep_attn<32>), reinterpret_cast<const void*>(&k_deep_attn<64>),
                         reinterpret_cast<const void*>(&k_conv_win<1, 4>), reinterpret_cast<const void*>(&k_conv_win<1, 2>),
-                        reinterpret_cast<const void*>(&k_conv_win<2, 2>)};
+                        reinterpret_cast<const void*>(&k_conv_win<2, 2>),
+                        reinterpret_cast<const void*>(&k_conv_pw<1, 1>), reinterpret_cast<const void*>(&k_conv_pw<1, 2>),
+                        reinterpret_cast<const void*>(&k_conv_pw<2, 1>), reinterpret_cast<const void*>(&k_conv_pw<2, 2>)};
     for (const void* f : fa) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1677,6 +1932,50 @@ hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s) {
     if (t.MT == 1 && t.NT == 4) return conv_win_launch_t<1, 4>(a, t.XM, s);
     if (t.MT == 1 && t.NT == 2) return conv_win_launch_t<1, 2>(a, t.XM, s);
     if (t.MT == 2 && t.NT == 2) return conv_win_launch_t<2, 2>(a, t.XM, s);
+    return hipErrorInvalidValue;
+}
+
+// ---- k_conv_pw (ConvTile{MT, NTW, NW = 96, KS = 1, XM = 0}) ----
+static size_t conv_pw_layout(const ConvArgs& a, int MT, int NTW) {
+    const int ROWS = 16 * MT, COLS = 128 * NTW;
+    const size_t stage = (size_t)ROWS * (a.Cmain + DEEP_PAD) + 384 + 192;          // rows | statistics (doubles) | (mean, rstd)
+    const size_t image = (size_t)ROWS * (COLS + 4) + DEEP_FIN_FLOATS;
+    return (stage > image ? stage : image) * 4 + 64;
+}
+bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW) {
+    if (!((MT == 1 || MT == 2) && (NTW == 1 || NTW == 2))) return false;       // (NTW = 3 measured slower than 1 and 2 on every shape: not built)
+    if (!a.Wnk || a.ntaps != 1 || a.nmain != 1 || a.nskip != 0 || a.Cskip != 0 || a.gather || a.gather_skip || a.geo_main || a.geo_skip) return false;
+    if (a.out_cm || a.ddim || a.bias_b || a.bias2) return false;
+    if ((a.Cmain & 15) || a.Cmain < 64 || a.Cmain > 512 || (512 % (a.Cmain >> 2)) || a.N % (16 * NTW) || a.Lsrc != a.Lout || (a.res && a.Lskip != a.Lout)) return false;
+    if (16 * MT > 8 * (512 / (a.Cmain >> 2)) * 2) return false;              // (rows beyond the first pass are fetched late: keep that to one extra pass)
+    for (int t = 0; t < a.nstat; ++t)
+        if (a.stat[t].coff & 3) return false;
+    if ((long)a.N * a.Cmain * 4 >= 0x7F000000L) return false;
+    return conv_pw_layout(a, MT, NTW) <= 160 * 1024;
+}
+size_t conv_pw_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_pw_layout(a, t.MT, t.NT); }
+
+template <int MT, int NTW>
+static hipError_t conv_pw_launch_t(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    if (!conv_pw_eligible(a, MT, NTW)) return hipErrorInvalidValue;
+    const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT), groups = (a.N + 128 * NTW - 1) / (128 * NTW);
+    a.KS = 1;
+    a.xmap = 0;
+    a.tiles_per_b = tiles;
+    a.tiles_n = groups;
+    a.Bt = a.B * tiles;
+    a.inv_tiles_per_b = 1.0f / (float)tiles;
+    a.inv_Bt = 1.0f / (float)a.Bt;
+    if ((long)a.Bt * groups >= (1L << 21)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_conv_pw<MT, NTW>), dim3((unsigned)(a.Bt * groups)), dim3(DEEP_NTH), conv_pw_layout(a, MT, NTW), s, a);
+    return hipGetLastError();
+}
+hipError_t launch_conv_pw(const ConvArgs& a, ConvTile t, hipStream_t s) {
+    if (t.MT == 1 && t.NT == 1) return conv_pw_launch_t<1, 1>(a, s);
+    if (t.MT == 1 && t.NT == 2) return conv_pw_launch_t<1, 2>(a, s);
+    if (t.MT == 2 && t.NT == 1) return conv_pw_launch_t<2, 1>(a, s);
+    if (t.MT == 2 && t.NT == 2) return conv_pw_launch_t<2, 2>(a, s);
     return hipErrorInvalidValue;
 }
 

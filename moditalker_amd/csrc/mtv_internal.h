@@ -379,6 +379,10 @@ hipError_t launch_split_w3(const float* W, void* W3, size_t plane_bytes, int row
 bool conv_win_eligible(const ConvArgs& a, int MT, int NT);
 size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s);
+// k_conv_pw<MT, NTW> (deep.hip): 1x1 conv on identity rows, rows normalised once into LDS, waves side by side along N (ConvTile NW = 96)
+bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW);
+size_t conv_pw_smem_bytes(const ConvArgs& a, ConvTile t);
+hipError_t launch_conv_pw(const ConvArgs& a, ConvTile t, hipStream_t s);
 bool conv_lin_eligible(const ConvArgs& a);
 size_t lin_smem_bytes(const ConvArgs& a);
 hipError_t launch_lin(const ConvArgs& a, ConvTile t, hipStream_t s);

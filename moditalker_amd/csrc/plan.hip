@@ -978,6 +978,7 @@ struct Builder {
 // LDS-tiled kernel k_conv_lds<WM, WN>; a conv that turns out not to be eligible at launch falls back (launch_conv)
 static int g_force_wm = -1, g_force_wn = 0;
 static int g_force_b3[3] = {-1, 0, 1};       // MTV_FORCE_B3="MT,NT[,KS]" (or mtv_debug_force_b3): every eligible conv on the split-bf16 kernel k_conv_x3<MT, NT>
+static int g_force_pw[2] = {-1, 0};         // MTV_FORCE_PW="MT,NTW" (or mtv_debug_force_pw): every eligible 1x1 conv on k_conv_pw<MT, NTW>
 static int g_force_win[2] = {-1, 0};        // MTV_FORCE_WIN="MT,NT" (or mtv_debug_force_win): every eligible 3x3 conv on k_conv_win<MT, NT>
 static int g_force_lin[3] = {-1, 0, 0};     // MTV_FORCE_LIN="MT,NT,NWV" (or mtv_debug_force_lin): every eligible 1x1 conv on k_lin<MT, NT, NWV>
 static void parse_force_b3() {
@@ -1022,6 +1023,14 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
         *t = ConvTile{g_force_win[0], g_force_win[1], 80, 1, xm};
         return;
     }
+    if (g_force_pw[0] == -1) {
+        g_force_pw[0] = 0;
+        if (const char* e = getenv("MTV_FORCE_PW")) {
+            int x = 0, y = 0;
+            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 1 || x == 2) && (y == 1 || y == 2)) { g_force_pw[0] = x; g_force_pw[1] = y; }
+        }
+    }
+    if (g_force_pw[0] > 0 && conv_pw_eligible(a, g_force_pw[0], g_force_pw[1])) { *t = ConvTile{g_force_pw[0], g_force_pw[1], 96, 1, 0}; return; }
     parse_force_b3();
     if (g_force_b3[0] > 0 && conv_x3_eligible(a) && conv_x3_smem_bytes(a, ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0}) <= CONV_X3_MAX_LDS) {
         const int nch32 = a.ntaps * (a.Cmain / 32) + a.Cskip / 32;
@@ -1128,7 +1137,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
     p->tuned = true;
     tune_cache_load(c);
     const char* env = getenv("MTV_AUTOTUNE");
-    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0 || g_force_lin[0] > 0 || g_force_b3[0] > 0 || g_force_win[0] > 0) return MTV_OK;
+    if ((env && atoi(env) == 0) || getenv("MTV_FORCE_TILE") || g_force_wm > 0 || g_force_lin[0] > 0 || g_force_b3[0] > 0 || g_force_win[0] > 0 || g_force_pw[0] > 0) return MTV_OK;
     static const int cand[][2] = {{4, 4}, {2, 4}, {1, 4}, {2, 2}, {1, 2}, {1, 1}};
     struct Events {             // destroyed on every exit path (HIPCHK returns early)
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1179,12 +1188,13 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
             const bool b3_ok = t.NW == 48 && !(a.B == 1 && a.Lout <= 2048) && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
             const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && (t.XM == 0 || t.XM == 1) && conv_win_eligible(a, t.MT, t.NT);
-            const bool shape_ok = tiled_ok || lin_ok || b3_ok || win_ok ||
+            const bool pw_ok = t.NW == 96 && t.KS == 1 && t.XM == 0 && conv_pw_eligible(a, t.MT, t.NT);
+            const bool shape_ok = tiled_ok || lin_ok || b3_ok || win_ok || pw_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
                                    t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1));
-            if (!shape_ok || (!tiled_ok && !lin_ok && !b3_ok && !win_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
-                (!b3_ok && !win_ok && conv_smem_bytes(a, t) > 120 * 1024)) {
+            if (!shape_ok || (!tiled_ok && !lin_ok && !b3_ok && !win_ok && !pw_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
+                (!b3_ok && !win_ok && !pw_ok && conv_smem_bytes(a, t) > 120 * 1024)) {
                 c->tune_cache.erase(it);
                 it = c->tune_cache.end();
             }
@@ -1319,6 +1329,30 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                         best = t;
                     }
                 }
+            }
+            // the 1x1 kernel of the large levels (deep.hip, k_conv_pw): rows normalised once into LDS, 8 waves side by side along N
+            if (a.ntaps == 1 && (long)a.B * a.Lout >= 256) {
+                for (int MT = 1; MT <= 2; ++MT)
+                    for (int NTW = 1; NTW <= 2; ++NTW) {
+                        if (!conv_pw_eligible(a, MT, NTW)) continue;
+                        const ConvTile t{MT, NTW, 96, 1, 0};
+                        if ((long)a.B * ((a.Lout + 16 * MT - 1) / (16 * MT)) * ((a.N + 128 * NTW - 1) / (128 * NTW)) < 48) continue;
+                        float samp[16];
+                        HIPCHK(run(t));
+                        for (int w = 0; w < nsamp; ++w) {
+                            HIPCHK(hipMemsetAsync(c->flush, w, c->flush_bytes, s));
+                            HIPCHK(hipEventRecord(e0, s));
+                            HIPCHK(run(t));
+                            HIPCHK(hipEventRecord(e1, s));
+                            HIPCHK(hipEventSynchronize(e1));
+                            HIPCHK(hipEventElapsedTime(&samp[w], e0, e1));
+                        }
+                        std::sort(samp, samp + nsamp);
+                        if (samp[nsamp / 2] < best_ms) {
+                            best_ms = samp[nsamp / 2];
+                            best = t;
+                        }
+                    }
             }
             // the lean 1x1 kernel (lin.hip): wave tile 16 MT x 16 NT, NWV waves side by side along N, whole K per wave
             if (conv_lin_eligible(a)) {
@@ -2004,6 +2038,13 @@ int mtv_debug_force_lin(int mt, int nt, int nwv) {
     if (mt == 0) { g_force_lin[0] = 0; return MTV_OK; }
     if (!((mt == 1 || mt == 2) && (nt == 1 || nt == 2 || nt == 4) && (nwv == 1 || nwv == 2 || nwv == 4))) return fail(MTV_ERR_INVALID, "k_lin tile must be {1,2} x {1,2,4} x {1,2,4}");
     g_force_lin[0] = mt; g_force_lin[1] = nt; g_force_lin[2] = nwv;
+    return MTV_OK;
+}
+
+int mtv_debug_force_pw(int mt, int ntw) {
+    if (mt == 0) { g_force_pw[0] = 0; return MTV_OK; }
+    if (!((mt == 1 || mt == 2) && (ntw == 1 || ntw == 2))) return fail(MTV_ERR_INVALID, "k_conv_pw tile must be {1, 2} x {1, 2}");
+    g_force_pw[0] = mt; g_force_pw[1] = ntw;
     return MTV_OK;
 }
 

@@ -592,3 +592,32 @@ def test_window_staged_conv_kernel_vs_reference_golden(mt, nt):
         assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
     finally:
         lib.mtv_debug_force_win(0, 0)
+
+
+@pytest.mark.parametrize("mt,ntw", [(1, 1), (1, 2), (2, 1), (2, 2)])
+def test_pointwise_conv_kernel_vs_reference_golden(mt, ntw):
+    """k_conv_pw (csrc/deep.hip: the rows of a tile normalised once into LDS, 8 waves side by side along N, weights in [N][K]) forced
+    onto every eligible 1x1 conv (qkv with its GroupNorm, proj_out with residual + statistics): eps and the 4-step sample of the base
+    UNet vs the reference golden, and a ragged two-clip geometry (partial row tiles, tiles that straddle planes) vs the oracle."""
+    from moditalker_amd import _lib
+    from oracle import ref_unet
+    lib = _lib.load()
+    _lib.check(lib.mtv_debug_force_pw(mt, ntw), "mtv_debug_force_pw")
+    try:
+        g = np.load(os.path.join(GOLDEN, "base.npz"))
+        net = _build(BASE_CFG, 7, max_batch=1)
+        dev = _dev()
+        x, cond, ic = filler.synthetic_inputs(1, 32, 16, seed=7, tag="base")
+        for tv in (999, 0):
+            eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([tv], device=dev))
+            assert _maxabs(eps, g[f"eps_t{tv}"]) <= FWD_TOL, tv
+        names = [p["name"] for p in net.diffusion_model.profile_forward(1, 1, dev)]
+        assert sum(",96,1]" in n for n in names) >= 20, "the pointwise kernel was not selected"
+        cfg = dict(BASE_CFG, image_size=24)            # 24x24 | 8x24 | 8x24 planes: ragged tiles at every level
+        net2 = _build(cfg, 21, frames=8, max_batch=2)
+        x, cond, ic = filler.synthetic_inputs(2, 24, 8, seed=5, tag="win")
+        t = torch.tensor([700, 3])
+        ref = ref_unet.unet_forward({k: v.cpu() for k, v in net2.state_dict().items()}, cfg, x, cond, ic, t, 24, 8)
+        assert _maxabs(net2(x.to(dev), cond.to(dev), ic.to(dev), t.to(dev)), ref) <= FWD_TOL
+    finally:
+        lib.mtv_debug_force_pw(0, 0)
