@@ -1355,7 +1355,10 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                     }
             }
             // the lean 1x1 kernel (lin.hip): wave tile 16 MT x 16 NT, NWV waves side by side along N, whole K per wave
-            if (conv_lin_eligible(a)) {
+            // (offered only with MTV_TUNE_LIN=1: in the step's graph its picks measured slower than k_conv's / k_conv_pw's on the same
+            // shapes -- profiles/r04_per_op_rocprof.txt -- although they win the tuner's cold, isolated timing)
+            static const bool tune_lin = getenv("MTV_TUNE_LIN") != nullptr;
+            if (tune_lin && conv_lin_eligible(a)) {
                 for (int MT = 1; MT <= 2; ++MT)
                     for (int NT = 1; NT <= 4; NT *= 2)
                         for (int NWV = 1; NWV <= 4; NWV *= 2) {
