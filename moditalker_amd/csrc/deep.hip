@@ -1505,7 +1505,11 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
         };
 #pragma unroll
         for (int u = 0; u < (2 * G > MAXR ? 2 * G : MAXR); ++u) {
-            if (u < 2 * G) wload1(bq[u / G][u % G], u);            // (every thread; chunks past K read as zeros without traffic)
+            // (every thread; chunks past K read as zeros without traffic.  Measured and dropped, profiles/r04_conv_pw_stamps.txt: all
+            // 2 G chunks requested with the rows -- they end up inside the wait of the statistics' first use, 8.75 -> 11.2 us per launch at
+            // [2048 x 384] -- or between the statistics barrier and the transform, 11.4 us: the tile then holds too many registers for two
+            // workgroups per CU.  The ~5k cycles to "rows parked" are the round trip of the rows themselves: every kernel starts on a cold L2)
+            if (u < 2 * G) wload1(bq[u / G][u % G], u);
             if (u < MAXR && stager && u * RP < ROWS) {
                 const int row = rl + u * RP;
                 if (row < ROWS) {

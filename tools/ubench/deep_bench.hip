@@ -554,6 +554,88 @@ static void do_win(int nops, int r, int t, int C) {
     for (const ConvTile& tl : tiles) run_tile(tl);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- k_conv_pw
+// 20 back-to-back launches of one qkv-shaped 1x1 conv ([L x K] -> [L x N], GroupNorm prologue, no statistics epilogue) in one hipGraph:
+// k_conv tiles against the k_conv_pw tiles, us per launch; stamps of the pw kernel
+static void do_pw(int r, int t, int K, int N) {
+    const int nops = 20, b1 = r * r, b2 = b1 + t * r, L = b2 + t * r, ldw = (N + 63) / 64 * 64;
+    printf("pw: %d launches of a 1x1 conv [%d x %d] -> [%d x %d] (r %d t %d), weights %.2f MB\n", nops, L, K, L, N, r, t, K * N * 4e-6);
+    std::vector<float> W((size_t)K * ldw, 0.f), Wnk((size_t)N * K), ones(K, 1.0f), zeros(N > K ? N : K, 0.f), x((size_t)L * K);
+    const float wsc = 1.0f / sqrtf((float)K);
+    for (auto& v : x) v = frand();
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) { const float v = frand() * wsc; W[(size_t)k * ldw + n] = v; Wnk[(size_t)n * K + k] = v; }
+    float *gamma = dup(ones), *beta = dup(zeros), *bias = dup(zeros), *dW = dup(W), *dWnk = dup(Wnk), *dx = dup(x);
+    float* dy = dnew<float>((size_t)L * N);
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    CK(conv_init_attrs());
+    CK(deep_init_attrs());
+    double* sites = dnew<double>((size_t)STAT_COPIES * 192);
+    float* slab = dnew<float>((size_t)16 * L * N);
+    int* tickets = dnew<int>(1 << 16);
+    unsigned long long* dbg = dnew<unsigned long long>(64);
+    {
+        std::vector<double> hs((size_t)STAT_COPIES * 192, 0.0);
+        for (int tok = 0; tok < L; ++tok)
+            for (int ch = 0; ch < K; ++ch) { const int p = tok >= b2 ? 2 : (tok >= b1 ? 1 : 0); const double v = x[(size_t)tok * K + ch]; hs[(p * 32 + ch / (K / 32)) * 2] += v; hs[(p * 32 + ch / (K / 32)) * 2 + 1] += v * v; }
+        CK(hipMemcpy(sites, hs.data(), hs.size() * 8, hipMemcpyHostToDevice));
+    }
+    ConvArgs a{};
+    a.src[0] = dx; a.C[0] = K; a.nmain = 1; a.Cmain = K; a.ntaps = 1; a.Lout = L; a.Lsrc = L; a.Lskip = L; a.B = 1;
+    a.W = dW; a.Wnk = dWnk; a.ldw = ldw; a.N = N; a.bias = bias; a.out = dy;
+    a.seg_src = SegInfo{b1, b2, L}; a.seg_out = a.seg_src; a.slab = slab; a.tickets = tickets;
+    a.gn = GnIn{sites, gamma, beta, nullptr, 0, K / 32, 0, 0, 192};
+    a.gn.inv_gs = 1.0f / (K / 32);
+    a.gn.inv_n[0] = 1.0 / ((double)b1 * (K / 32)); a.gn.inv_n[1] = 1.0 / ((double)(b2 - b1) * (K / 32)); a.gn.inv_n[2] = 1.0 / ((double)(L - b2) * (K / 32)); a.gn.inv_n[3] = 1.0 / ((double)L * (K / 32));
+    a.nstat = 0; a.stat_cstride = 192;
+    a.dbg = dbg;
+    std::vector<float> ref;
+    auto run_tile = [&](ConvTile tile) {
+        if (tile.NW == 96 && !conv_pw_eligible(a, tile.MT, tile.NT)) return;
+        if (tile.NW != 96 && (conv_smem_bytes(a, tile) > 120 * 1024 || tile.NW * tile.KS > K / 16)) return;
+        hipGraph_t gr; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        for (int o = 0; o < nops; ++o) CK(launch_conv(a, tile, s));
+        CK(hipStreamEndCapture(s, &gr));
+        CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        std::vector<float> got((size_t)L * N);
+        CK(hipMemcpy(got.data(), dy, got.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0;
+        if (ref.empty()) ref = got;
+        else for (size_t e = 0; e < got.size(); ++e) worst = std::max(worst, (double)fabsf(got[e] - ref[e]));
+        for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, s));
+        const int reps = 30;
+        for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, s));
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  tile %d,%d,%d,%d,%d  %7.2f us per launch   (max|diff| to the first tile %.2e)\n", tile.MT, tile.NT, tile.NW, tile.KS, tile.XM, ms * 1e3 / reps / nops, worst);
+#ifdef MTV_DEEP_STAMP
+        if (tile.NW == 96) {
+            unsigned long long h[64];
+            CK(hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
+            static const char* nm[10] = {"entry", "decoded", "requests issued", "stats barrier", "stats2", "rows parked", "mfma done", "image", "-", "end"};
+            static const int order[] = {1, 2, 3, 4, 5, 6, 7, 9, -1};
+            for (int blk = 0; blk < 2; ++blk)
+                for (int role = 0; role < 2; ++role) {
+                    printf("    stamps wg %s %s:", blk ? "mid" : "0", role ? "wave 4" : "wave 0");
+                    for (int k = 0; order[k] >= 0; ++k) printf("  %s %lld", nm[order[k]], (long long)(h[blk * 32 + role * 16 + order[k]] - h[blk * 32 + role * 16]));
+                    printf("\n");
+                }
+        }
+#endif
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(gr));
+    };
+    const ConvTile tiles[] = {{2, 4, 4, 1, 0}, {1, 4, 4, 1, 0}, {1, 4, 8, 1, 0}, {1, 2, 4, 1, 0}, {1, 2, 8, 1, 0}, {1, 1, 96, 1, 0}, {2, 1, 96, 1, 0}, {1, 2, 96, 1, 0}, {2, 2, 96, 1, 0}};
+    for (const ConvTile& tl : tiles) run_tile(tl);
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && !strcmp(argv[1], "check")) { CK(deep_init_attrs()); return do_check(); }
     if (argc >= 2 && !strcmp(argv[1], "chain")) {
@@ -564,6 +646,10 @@ int main(int argc, char** argv) {
     }
     if (argc >= 2 && !strcmp(argv[1], "win")) {
         do_win(argc >= 3 ? atoi(argv[2]) : 20, argc >= 5 ? atoi(argv[3]) : 32, argc >= 5 ? atoi(argv[4]) : 16, argc >= 6 ? atoi(argv[5]) : 128);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "pw")) {
+        do_pw(argc >= 4 ? atoi(argv[2]) : 32, argc >= 4 ? atoi(argv[3]) : 16, argc >= 5 ? atoi(argv[4]) : 128, argc >= 6 ? atoi(argv[5]) : 384);
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "attn")) { CK(deep_init_attrs()); return do_attn(argc >= 3); }
