@@ -215,7 +215,8 @@ def main():
                     bytes=fam.get("conv3", {}).get("bytes", 0) + fam.get("conv1", {}).get("bytes", 0),
                     launches=fam.get("conv3", {}).get("launches", 0) + fam.get("conv1", {}).get("launches", 0))
         attn = fam.get("attn", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        # (the conv family = k_conv + the K-sliced k_deep_conv of the <= 128-token levels: op names "conv3:" / "conv1:" either way)
+        # (the conv family = k_conv, the window-staged k_conv_win, the pointwise k_conv_pw and the K-sliced k_deep_conv of the <= 128-token
+        # levels: op names "conv3:" / "conv1:" whichever kernel the tile table names)
         deep = dict(ms=0.0, flops=0.0, bytes=0.0, launches=0)
         for p in prof:
             if p["name"].startswith("conv") and " d" in p["name"].split("[")[-1]:
@@ -248,7 +249,7 @@ def main():
             hbm_counter_GBs = round((2.0 * ec["fetch_raw_MB_per_step"] + ec["write_raw_MB_per_step"]) * 1e6 / (conv["ms"] * 1e-3) / 1e9, 1)
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
-        roofline = dict(bound="mfma", kernel=dom_name if dom_name != "k_conv" else "k_conv + k_deep_conv (every conv launch)", achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TF,
+        roofline = dict(bound="mfma", kernel=dom_name if dom_name != "k_conv" else "k_conv / k_conv_win / k_conv_pw + k_deep_conv (every conv launch)", achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TF,
                         unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TF, 4), traffic=traffic, traffic_unit="bytes/launch",
                         traffic_source=traffic_src,
                         launches_per_step=dom["launches"], avg_launch_us=round(1e3 * dom["ms"] / max(1, dom["launches"]), 3),
@@ -277,6 +278,11 @@ def main():
         families = {k: dict(ms_per_step=round(v["ms"], 4), launches=v["launches"],
                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] else None)
                     for k, v in fam.items()}
+        for tagk, label in ((",80,", "conv3_window_staged(k_conv_win)"), (",96,", "conv1_pointwise(k_conv_pw)")):
+            sel = [p for p in prof if p["name"].startswith("conv") and tagk in p["name"].split("[")[-1]]
+            if sel:
+                ms = max(1e-6, sum(p["ms"] for p in sel) - ev_ms * len(sel))
+                families[label] = dict(ms_per_step=round(ms, 4), launches=len(sel), tflops=round(sum(p["flops"] for p in sel) / (ms * 1e-3) / 1e12, 2))
         if deep["launches"]:
             # the weight-streaming convs of the deep levels on their own: algorithmic bytes (weights once + activations) per second
             families["conv_deep_levels(k_deep_conv)"] = dict(ms_per_step=round(deep["ms"], 4), launches=deep["launches"],
