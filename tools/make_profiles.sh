@@ -75,6 +75,10 @@ timeout 300 tools/ubench/deep_bench attn >> $O/r${NN}_deep_check.txt 2>&1
 if [ -x tools/ubench/deep_bench_stamp ]; then DB=tools/ubench/deep_bench_stamp; else DB=tools/ubench/deep_bench; fi
 (for cfg in "40 4 2" "40 8 4" "16 4 2" "16 8 4"; do timeout 120 $DB chain $cfg 2>&1 | grep -v "final act"; done) > $O/r${NN}_deep_chain.txt
 timeout 120 $DB attn time 2>&1 | grep -v "^ATTN" > $O/r${NN}_deep_attn.txt
+# 10b. the level-0/1 kernels in chains: k_conv tiles vs k_conv_win tiles (20 dependent 3x3 convs) and vs k_conv_pw tiles (20 qkv-shaped 1x1
+#      launches), with stamps (the r04_conv_win_stamps.txt / r04_conv_pw_stamps.txt of round 4 are these commands run across kernel versions)
+(timeout 120 $DB win 20 32 16 128; timeout 120 $DB win 20 16 8 256) > $O/r${NN}_conv_win_chain.txt 2>&1
+(timeout 120 $DB pw 32 16 128 384; timeout 120 $DB pw 16 8 256 768; timeout 120 $DB pw 16 8 512 1536) > $O/r${NN}_conv_pw_chain.txt 2>&1
 # 11. one page of numbers, written by a script from the files above (no hand-typed figures)
 python tools/round_summary.py $NN $O > $O/r${NN}_summary.md 2>$O/summary.err
 rm -rf $O/kt $O/ktae $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
