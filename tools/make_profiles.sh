@@ -61,7 +61,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktae -o k
 cp "$(find $O/ktae -name '*kernel_stats.csv' | head -1)" $O/r${NN}_ae_decode_rocprofv3_kernel_stats.csv
 # 8. the in-kernel phase anatomy of every conv and every attention launch of a step (diagnostic build with s_memtime
 #    stamps: MTV_BUILD_STAMP=1 bash moditalker_amd/csrc/build.sh)
-MTV_LIB=$PWD/moditalker_amd/csrc/libmtv_hip_stamp.so MTV_STAMPS=1 timeout 300 python tools/stamps.py > $O/stamps_all.txt 2>/dev/null
+#    (a twin older than the library lacks its newest C-ABI symbols and fails to load: rebuild it first)
+[ moditalker_amd/csrc/libmtv_hip_stamp.so -nt moditalker_amd/csrc/plan.hip ] || MTV_BUILD_STAMP=1 bash moditalker_amd/csrc/build.sh > $O/build_stamp.log 2>&1
+MTV_LIB=$PWD/moditalker_amd/csrc/libmtv_hip_stamp.so MTV_STAMPS=1 timeout 300 python tools/stamps.py > $O/stamps_all.txt 2>$O/stamps.err
+[ -s $O/stamps_all.txt ] || { echo "stamps.py produced nothing:"; tail -5 $O/stamps.err; }
 sed -n '/^# attention/,$p' $O/stamps_all.txt > $O/r${NN}_attention_phase_stamps.txt
 sed '/^# attention/,$d' $O/stamps_all.txt > $O/r${NN}_conv_phase_stamps.txt
 # 9. micro-benchmarks: the launch chain, f32 MFMA vs VALU on one SIMD
