@@ -19,6 +19,7 @@
 namespace mtv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
@@ -362,13 +363,16 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
             }
         }
     };
-    auto lstore = [&](int buf, int kb) {
+    // (all_tag: every key of the tile exists -- all tiles but possibly the last: no per-row selects, the softmax's VALU is the
+    // kernel's bottleneck (profiles/r04_attention_phase_stamps.txt))
+    auto lstore = [&](int buf, int kb, auto all_tag) {
+        constexpr bool ALL = decltype(all_tag)::value;
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
             const int e = tid + NTH * r;
             const int key = e / QPR, qd = e - key * QPR;
             if (e < KB * QPR) {
-                const bool in = kb + key < klen;
+                const bool in = ALL || kb + key < klen;
                 const f32x4 kq = in ? kreg[r] * scale : f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (QB) {       // three bf16 terms of the 4 values, 8 bytes per plane
                     unsigned p0[2], p1[2], p2[2];
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < VW; ++e) qreg[u][e] = qok ? qraw[u][e] * scale * LOG2E : 0.f;   // scores in log2 units
     }
-    lstore(0, 0);
+    lstore(0, 0, std::false_type{});
     __syncthreads();
     ATT_STAMP(2);
     int buf = 0;
@@ -542,15 +546,20 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         const bool live = FULL || mn != -INFINITY;      // a key-split wave may see only masked keys so far
         const float alpha = live ? __builtin_amdgcn_exp2f(m - mn) : 1.0f;
         m = mn;
-        float ps = 0.f;
+        // (pairs: s - m and the row sum as two-wide packed f32 operations -- v_pk_add_f32 -- around the scalar v_exp_f32)
+        f32x2 ps2 = {0.f, 0.f};
+        const f32x2 mn2 = {mn, mn};
 #pragma unroll
         for (int w = 0; w < WKT; ++w)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = live ? __builtin_amdgcn_exp2f(st[w][r] - mn) : 0.f;
-                st[w][r] = p;
-                ps += p;
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 dlt = f32x2{st[w][r], st[w][r + 1]} - mn2;
+                const f32x2 p = {live ? __builtin_amdgcn_exp2f(dlt[0]) : 0.f, live ? __builtin_amdgcn_exp2f(dlt[1]) : 0.f};
+                st[w][r] = p[0];
+                st[w][r + 1] = p[1];
+                ps2 += p;
             }
+        const float ps = ps2[0] + ps2[1];
         lsum = lsum * alpha + ps;
         // O^T += V^T P^T : A = V^T rows (d index) x keys, read as 4 consecutive keys per lane.  Independent accumulators
         // round-robin again: the NOB output blocks, or (one block: d <= 16) the even / odd key tiles of the wave.
@@ -590,7 +599,10 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         else if (kb + KB <= klen) block(kb, std::integral_constant<int, 0>{});
         else block(kb, std::integral_constant<int, 1>{});
         ATT_ACC(att_tb);
-        if (more) lstore(buf ^ 1, kb + KB);
+        if (more) {
+            if (kb + 2 * KB <= klen) lstore(buf ^ 1, kb + KB, std::true_type{});
+            else lstore(buf ^ 1, kb + KB, std::false_type{});
+        }
         ATT_ACC(att_tw);
         __syncthreads();
         ATT_ACC(att_ts);
