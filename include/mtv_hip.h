@@ -204,6 +204,11 @@ int mtv_selftest_geometry(int res, int frames, int n_levels);
  * im2col tables (unet.py:178-207 ResBlock convs incl. the Upsample of :531-598).  0 = all agree, else 1 + the first level that
  * does not (<0: bad arguments). */
 int mtv_selftest_deep(int res, int frames, int n_levels);
+/* Host-only self-test of k_conv_win's window arithmetic (csrc/deep.hip: the contiguous range of source tokens a row tile of a 3x3
+ * conv stages in LDS): for row tiles of 16 and 32 tokens at every level, same-level and nearest-upsampled source, the window lies inside
+ * the source tensor and contains the source token of every tap of every output row (the taps of mtv_debug_gather_index).  0 = ok,
+ * else 1 + the first level that fails (<0: bad arguments). */
+int mtv_selftest_win(int res, int frames, int n_levels);
 /* The arithmetic itself, for tests: source token of tap (ky, kx in 0..2) at output token `tok` of a level with
  * planes res x res | frames x res | frames x res; up != 0: the source is the (res/2, frames/2) level under a
  * nearest x2 upsample.  Returns -1 for zero padding, else source_token | plane << 28. */

@@ -1884,6 +1884,27 @@ static size_t conv_win_layout(const ConvArgs& a, int MT, int NT, int* wcap_out) 
     const size_t red = (size_t)8 * ROWS * (COLS + 4) + DEEP_FIN_FLOATS;
     return (fl > red ? fl : red) * 4 + 64;
 }
+// Host-only check of conv_win_window (the arithmetic the kernel and the LDS sizing share): for both row-tile heights and every row
+// tile of a level, the window lies inside the source tensor, is no taller than 16 MT + 2 r + 2 rows, and contains the source token of
+// every tap of every output row of the tile.  0 = ok.
+int conv_win_selftest(int r, int t, bool up, int Lout, int Lsrc) {
+    for (int rows = 16; rows <= 32; rows += 16)
+        for (int tok0 = 0; tok0 < Lout; tok0 += rows) {
+            int lo = 0, n = 0;
+            conv_win_window(r, t, up, Lout, tok0, rows, &lo, &n);
+            if (lo < 0 || n < 1 || lo + n > Lsrc) return 1;
+            if (!up && n > rows + 2 * r + 2) return 2;
+            for (int ri = 0; ri < rows && tok0 + ri < Lout; ++ri)
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int g = geo_source(r, t, tok0 + ri, tap / 3, tap % 3, up);
+                    if (g < 0) continue;
+                    const int src = g & 0x0FFFFFFF;
+                    if (src < lo || src >= lo + n) return 3;
+                }
+        }
+    return 0;
+}
+
 bool conv_win_eligible(const ConvArgs& a, int MT, int NT) {
     if (!((MT == 1 && (NT == 2 || NT == 4)) || (MT == 2 && NT == 2))) return false;       // (2 x 4 spills at 512 threads)
     if (a.ntaps != 9 || (a.geo_main != 1 && a.geo_main != 2) || a.out_cm || a.ddim || a.N % (16 * NT) || (a.Cmain & 15) || (a.Cskip & 15) || a.Cmain > 2048) return false;

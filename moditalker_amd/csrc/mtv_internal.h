@@ -377,6 +377,7 @@ hipError_t launch_conv_x3_geglu(const ConvArgs& a, ConvTile t, const float* h, h
 hipError_t launch_split_w3(const float* W, void* W3, size_t plane_bytes, int row0, int rows, int ldw, hipStream_t s);
 // k_conv_win (deep.hip): 3x3 convs of the large levels with the transformed input window staged in LDS -- ConvTile NW == 80
 bool conv_win_eligible(const ConvArgs& a, int MT, int NT);
+int conv_win_selftest(int r, int t, bool up, int Lout, int Lsrc);      // host-only check of the window arithmetic (0 = ok)
 size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s);
 // k_conv_pw<MT, NTW> (deep.hip): 1x1 conv on identity rows, rows normalised once into LDS, waves side by side along N (ConvTile NW = 96)

@@ -1953,6 +1953,19 @@ int mtv_selftest_geometry(int res, int frames, int n_levels) {
 /* Host-only self-test of the deep levels' row tables (deep.hip, deep_rowtab): for every level of at most 128 tokens, every row grouping
  * and tap count, and the upsampling variant, each table entry must name the source token the explicitly constructed im2col tables
  * name (or the zero row where they pad).  0 = all agree, else 1 + the level that does not. */
+int mtv_selftest_win(int res, int frames, int n_levels) {
+    if (res <= 0 || frames <= 0 || n_levels <= 0 || n_levels > 8 || (res >> (n_levels - 1)) <= 0 || (frames >> (n_levels - 1)) <= 0)
+        return fail(MTV_ERR_INVALID, "selftest_win: bad geometry");
+    const std::vector<Level> lv = make_levels(res, frames, n_levels);
+    for (int l = 0; l < n_levels; ++l)
+        for (int up = 0; up < 2; ++up) {
+            if (up && l + 1 >= n_levels) continue;
+            const Level& src = up ? lv[l + 1] : lv[l];
+            if (conv_win_selftest(lv[l].r, lv[l].t, up != 0, lv[l].L, src.L) != 0) return l + 1;
+        }
+    return 0;
+}
+
 int mtv_selftest_deep(int res, int frames, int n_levels) {
     if (res <= 0 || frames <= 0 || n_levels <= 0 || n_levels > 8 || (res >> (n_levels - 1)) <= 0 || (frames >> (n_levels - 1)) <= 0)
         return fail(MTV_ERR_INVALID, "selftest_deep: bad geometry");

@@ -250,3 +250,14 @@ def test_deep_level_row_tables_match_im2col_tables(R, T, levels):
     lib = _lib.load()
     assert lib.mtv_selftest_deep(R, T, levels) == 0
     assert lib.mtv_selftest_deep(0, 4, 2) < 0            # bad arguments are an error, not a pass
+
+
+@pytest.mark.parametrize("R,T,levels", [(32, 16, 4), (64, 16, 4), (8, 4, 3), (16, 8, 4), (24, 8, 3), (16, 8, 2), (48, 12, 3)])
+def test_window_staged_conv_window_covers_every_tap(R, T, levels):
+    """csrc/deep.hip, k_conv_win: the contiguous source-token window a row tile stages in LDS (conv_win_window, shared by the host's
+    LDS sizing and the kernel) contains the source of every 3x3 tap of every row of the tile, at every level, for 16- and 32-row tiles,
+    same-level and nearest-upsampled sources, and stays inside the source tensor (host only, through the C ABI)."""
+    from moditalker_amd import _lib
+    lib = _lib.load()
+    assert lib.mtv_selftest_win(R, T, levels) == 0
+    assert lib.mtv_selftest_win(0, 4, 2) < 0
