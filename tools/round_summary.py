@@ -69,3 +69,10 @@ if dc:
     print("## Deep-level kernels on their own (tools/ubench/deep_bench)\n\n```")
     print("\n".join(l for l in dc.splitlines() if not l.lstrip().startswith("stamps")))
     print("```")
+for name, title in ((f"r{nn}_conv_win_chain.txt", "k_conv tiles vs k_conv_win tiles, 20 dependent 3x3 convs in one graph (deep_bench win; tile = MT,NT,NW,KS,XM, NW 80 = k_conv_win)"),
+                    (f"r{nn}_conv_pw_chain.txt", "k_conv tiles vs k_conv_pw tiles, 20 launches of a qkv-shaped 1x1 conv in one graph (deep_bench pw; NW 96 = k_conv_pw)")):
+    t = rd(name)
+    if t:
+        print(f"\n## {title}\n\n```")
+        print("\n".join(l for l in t.splitlines() if not l.lstrip().startswith("stamps") and not l.startswith("+ ")))
+        print("```")
