@@ -94,6 +94,8 @@ def main():
                          "happen outside the timed region; set-up, not steps")
     ap.add_argument("--no-autoencoder", action="store_true",
                     help="skip the informational autoencoder timings (decode_from_sample / extract of one 16-frame 256x256 clip)")
+    ap.add_argument("--no-res64", action="store_true",
+                    help="skip the informational configs[3] (R = 64) timing that rides in the default line as res64_info")
     ap.add_argument("--res", type=int, default=32, choices=(32, 64),
                     help="latent resolution R: 32 = BASELINE configs[1] (the metric's workload), 64 = configs[3] (512x512 clip)")
     args = ap.parse_args()
@@ -238,9 +240,12 @@ def main():
         # HBM bytes per launch from the PMC passes (cannot be collected inside this process): the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summaries of this same command, gfx950 correction applied
         # (a constant of the committed profile, NOT a measurement of this run: `traffic_source.kind` says so)
+        # The file is keyed by workload ("R32" = configs[1], "R64" = configs[3]): a workload without a committed pass prints
+        # traffic / counters as null, never another workload's constants.
         traffic, traffic_src, pmc, hbm_counter_GBs = None, None, {}, None
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            pmc_all = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            pmc = dict(pmc_all["workloads"][f"R{R}"], source=pmc_all["source"])
             e = pmc[dom_name]
             traffic = round((2.0 * e["fetch_raw_MB_per_step"] + e["write_raw_MB_per_step"]) * 1e6 / e["launches_per_step"])
             traffic_src = dict(kind="committed", collected=pmc.get("collected"), commit=pmc.get("commit"), detail=pmc["source"])
@@ -259,7 +264,7 @@ def main():
                         flops_per_step=dom["flops"],
                         hbm_counter_GBs=hbm_counter_GBs,            # conv family: (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes) / this run's family time
                         mfma_util_counter=pmc.get("k_conv", {}).get("mfma_util"),   # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles (committed PMC pass, tools/pmc_util.py)
-                        counter_kind="committed")
+                        counter_kind="committed" if traffic is not None else None)
         # the HBM side of the same family, with BOTH byte definitions: SURVEY section 8(d)'s "fused conv/GN path"
         # (3x3 conv weights + fused 1x1 skip weights + their activations: 477 MB at configs[1]) and this build's wider
         # one (every k_conv launch incl. qkv/proj: weights once + activations in/out once)
@@ -275,6 +280,15 @@ def main():
                             algorithmic_bytes_per_step=dom["bytes"] if dom_name == "k_conv" else conv["bytes"],
                             achieved_GBs=round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9, 1) if conv["ms"] > 0 else 0.0,
                             frac=round(conv["bytes"] / (conv["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if conv["ms"] > 0 else 0.0))
+        if deep["launches"] and deep["ms"] > 0:
+            # the only HBM-shaped part of the path at one clip per GPU: the weight-streaming 3x3 convs of the <= 128-token levels
+            # (unet.py:178-207 at levels 2 / 3): algorithmic bytes (weights once + activations in / out once) over their launch time
+            roofline["hbm_view"]["deep_levels"] = dict(
+                what="k_deep_conv launches (3x3 convs of the <= 128-token levels): weights once + activations in/out once",
+                launches=deep["launches"], algorithmic_bytes_per_step=deep["bytes"], ms_per_step=round(deep["ms"], 4),
+                achieved_GBs=round(deep["bytes"] / (deep["ms"] * 1e-3) / 1e9, 1),
+                frac=round(deep["bytes"] / (deep["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            roofline["hbm_view"]["headline"] = "deep_levels"
         families = {k: dict(ms_per_step=round(v["ms"], 4), launches=v["launches"],
                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] else None)
                     for k, v in fam.items()}
@@ -320,51 +334,50 @@ def main():
                         break
                 return img, done
 
-            # Two figures, both labelled.  `value`: >= 10 timed steps after 2 warm-up steps (BASELINE.md section 3's run length) at the
-            # thread count this B=1 workload actually scales to (oneDNN / bmm at 2048 tokens stop scaling at 8-32 threads; the best
-            # of a 1-step probe) -- `cores` is that count.  `physical_cores_rule`: BASELINE.md section 3's thread rule,
-            # torch.set_num_threads(<physical cores>), under a time budget (on some boxes 128 oracle threads crawl at 30-50 s per
-            # step: the default run must still finish within minutes) -- reported beside it, never instead of it.
+            # Two figures, both labelled.  `value`: BASELINE.md section 3's rule -- torch.set_num_threads(<physical cores of the box>),
+            # >= 10 timed steps after warm-up, under a time budget (on some boxes 128 oracle threads crawl at 30-50 s per step: the
+            # default run must still finish within minutes; `sample` says how many steps the budget allowed) -- `cores` = that count.
+            # `best_threads`: the same loop at the thread count this B=1 workload actually scales to (oneDNN / bmm at 2048 tokens
+            # stop scaling at 8-32 threads; the best of a 1-step probe) -- reported beside it, never instead of it.
             model = ""
             try:
                 model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
             except (OSError, IndexError):
                 pass
+            n_timed = max(10, args.cpu_steps)
+            torch.set_num_threads(ncores)
+            tw = time.perf_counter()
+            cpu_steps(1, xc)                      # warm-up at the physical-core count (allocator, oneDNN primitives)
+            tw = time.perf_counter() - tw
+            if tw < 45.0:
+                cpu_steps(1, xc)                  # (second warm-up step)
+                tp = time.perf_counter()
+                _, pdone = cpu_steps(n_timed, xc, budget_s=30.0)
+                tp = time.perf_counter() - tp
+                phys_value, phys_sample = pdone / tp, f"{pdone} timed steps after 2 warm-up steps (30 s budget)"
+            else:
+                phys_value, phys_sample = 1.0 / tw, f"one un-warmed step took {tw:.0f} s: not repeated"
             cand = sorted({t for t in (8, 16, 32) if t <= ncores}) or [ncores]
             probe = {}
             for tcount in cand:
                 torch.set_num_threads(tcount)
-                cpu_steps(1, xc)                  # (allocator, oneDNN primitives)
+                cpu_steps(1, xc)
                 t1 = time.perf_counter()
                 cpu_steps(1, xc)
                 probe[tcount] = time.perf_counter() - t1
             best_t = min(probe, key=probe.get)
             torch.set_num_threads(best_t)
-            n_timed = max(10, args.cpu_steps)
             cpu_steps(2, xc)                      # the 2 warm-up steps
             tc = time.perf_counter()
-            _, cpu_done = cpu_steps(n_timed, xc, budget_s=60.0)
+            _, cpu_done = cpu_steps(n_timed, xc, budget_s=30.0)
             tc = time.perf_counter() - tc
-            torch.set_num_threads(ncores)
-            tw = time.perf_counter()
-            cpu_steps(1, xc)                      # warm-up at this thread count
-            tw = time.perf_counter() - tw
-            phys = None
-            if tw < 45.0:
-                tp = time.perf_counter()
-                _, pdone = cpu_steps(n_timed, xc, budget_s=30.0)
-                tp = time.perf_counter() - tp
-                phys = dict(threads=ncores, value=round(pdone / tp, 4), steps=pdone,
-                            sample=f"{pdone} timed steps after 1 warm-up step, 30 s budget, torch.set_num_threads({ncores}) = physical cores")
-            else:
-                phys = dict(threads=ncores, value=round(1.0 / tw, 4), steps=1,
-                            sample=f"one un-warmed step took {tw:.0f} s at torch.set_num_threads({ncores}): not repeated")
-            cpu = dict(value=round(cpu_done / tc, 4), unit="denoise-steps/s", cores=best_t, kind="port",
-                       sample=f"{cpu_done} timed steps (the first of the 250 DDIM steps of the same clip) after 2 warm-up steps at torch.set_num_threads({best_t}), "
-                              f"the best of a 1-step probe over {cand} threads; oracle/ref_unet.py op-for-op PyTorch {torch.__version__} CPU restatement, "
-                              f"fp32; {os.cpu_count()} logical CPUs, {model}",
-                       thread_probe_s_per_step={str(k): round(v, 3) for k, v in probe.items()},
-                       physical_cores_rule=phys)
+            cpu = dict(value=round(phys_value, 4), unit="denoise-steps/s", cores=ncores, kind="port",
+                       sample=f"{phys_sample} at torch.set_num_threads({ncores}) = physical cores (BASELINE.md section 3); the first of the 250 DDIM "
+                              f"steps of the same clip; oracle/ref_unet.py op-for-op PyTorch {torch.__version__} CPU restatement, fp32; "
+                              f"{os.cpu_count()} logical CPUs, {model}",
+                       best_threads=dict(threads=best_t, value=round(cpu_done / tc, 4), steps=cpu_done,
+                                         sample=f"{cpu_done} timed steps after 2 warm-up steps at the best of a 1-step probe over {cand} threads",
+                                         thread_probe_s_per_step={str(k): round(v, 3) for k, v in probe.items()}))
         # ---- informational only: the same loop with several clips batched on this GPU (amortises the
         # per-launch floor and the weight stream; NOT the BASELINE workload, never `value`)
         batched = None
@@ -403,6 +416,50 @@ def main():
                            k_attention_frac_of_f32_mfma_peak=round(afl / ams / 1e9 / MFMA_F32_PEAK_TF, 3))
             del netb, dmb
             gpu_sections["batched_info"] = time.perf_counter() - t_sec
+        # ---- informational only: BASELINE configs[3] (16-frame 512x512 clip: R = 64, L = 6144 tokens, B = 1) in the same line, so that the
+        # driver's default run carries a number for it (`python bench.py --res 64` makes it the line's own workload); never `value`
+        res64 = None
+        if world == 1 and R == 32 and not args.no_res64:
+            t_sec = time.perf_counter()
+            R6 = 64
+            L6 = R6 * R6 + 2 * T * R6
+            net6 = DiffusionWrapper(UNetModel(**dict(BASE_UNET_CONFIG, image_size=R6), frames=T, max_batch=1)).eval().to(dev)
+            net6.load_state_dict(net.state_dict())          # (no parameter of the UNet depends on the latent resolution)
+            dm6 = DDPM(net6, channels=4, image_size=R6, sampling_timesteps=S, w=0.0).to(dev)
+            ctx6 = net6.diffusion_model.hip_context(dev, 1)
+            c6 = torch.rand(1, 8, L6, generator=g, device=dev) * 2 - 1
+            i6 = torch.rand(1, 4, R6 * R6, generator=g, device=dev) * 2 - 1
+            ns6 = 40
+            n6 = torch.randn(ns6, 1, 4, L6, generator=g, device=dev)
+
+            def run6(nsteps):
+                x6 = torch.randn(1, 4, L6, generator=g, device=dev)
+                stp, _ = cycled_steps(dm6, nsteps)
+                _lib.check(lib.mtv_ddim_sample(ctx6, x6.data_ptr(), c6.data_ptr(), i6.data_ptr(), R6 * R6, n6.data_ptr(), ns6,
+                                               stp, nsteps, 1, C.c_void_p(stream.cuda_stream)), "mtv_ddim_sample")
+
+            run6(ns6)                                        # plan, graphs, clocks
+            torch.cuda.synchronize(dev)
+            t6 = time.perf_counter()
+            run6(ns6)
+            torch.cuda.synchronize(dev)
+            t6 = time.perf_counter() - t6
+            p6 = net6.diffusion_model.profile_forward(1, 3, dev, step=True)
+            cms = sum(p["ms"] for p in p6 if p["name"].startswith("conv"))
+            cfl = sum(p["flops"] for p in p6 if p["name"].startswith("conv"))
+            ams = sum(p["ms"] for p in p6 if p["name"].startswith("attn"))
+            afl = sum(p["flops"] for p in p6 if p["name"].startswith("attn"))
+            ev6 = max(0.0, (sum(p["ms"] for p in p6) - 1e3 * t6 / ns6) / max(1, len(p6)))      # event overhead per launch, as above
+            cms = max(1e-6, cms - ev6 * sum(1 for p in p6 if p["name"].startswith("conv")))
+            ams = max(1e-6, ams - ev6 * sum(1 for p in p6 if p["name"].startswith("attn")))
+            res64 = dict(workload=f"configs[3]: 16-frame 512x512 clip = tri-plane latent [1,4,{L6}] (R=64,T=16), same UNet, B=1",
+                         steps=ns6, steps_per_s=round(ns6 / t6, 2), ms_per_step=round(1e3 * t6 / ns6, 3), launches_per_step=len(p6),
+                         conv_tflops=round(cfl / cms / 1e9, 2), conv_frac_of_f32_mfma_peak=round(cfl / cms / 1e9 / MFMA_F32_PEAK_TF, 3),
+                         attention_tflops=round(afl / ams / 1e9, 2), attention_frac_of_f32_mfma_peak=round(afl / ams / 1e9 / MFMA_F32_PEAK_TF, 3),
+                         note=f"{ns6} timed steps after {ns6} untimed; fractions from hipEvents around every launch of one step; "
+                              "counters for this workload: `python bench.py --res 64` (roofline.traffic there)")
+            del net6, dm6
+            gpu_sections["res64_info"] = time.perf_counter() - t_sec
         # ---- informational only: the steps either side of the loop (BASELINE configs[4]'s decode tail, section 8 f-1/f-2),
         # one 16-frame 256x256 clip through the HIP autoencoder (recipe-filled weights; never part of `value`)
         ae_info = None
@@ -442,7 +499,7 @@ def main():
                          peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches_per_step=attn["launches"], flops_per_step=attn["flops"])
         attn_roof["frac"] = round(attn_roof["achieved"] / MFMA_F32_PEAK_TF, 4)
         attn_roof["mfma_util_counter"] = pmc.get("k_attention", {}).get("mfma_util")   # matrix-pipe busy fraction from SQ counters (committed pass)
-        attn_roof["counter_kind"] = "committed"
+        attn_roof["counter_kind"] = "committed" if attn_roof["mfma_util_counter"] is not None else None
         result = {
             "metric": f"denoise-steps/sec (16-frame {8 * R}^2 clip, 250 DDIM steps)",
             "value": round(world * K / dt, 3),
@@ -479,6 +536,7 @@ def main():
             "families": families,
             "roofline_attention": attn_roof,
             "batched_info": batched,
+            "res64_info": res64,
             "autoencoder_info": ae_info,
         }
     barrier()

@@ -320,6 +320,7 @@ struct Builder {
         const bool on = g_deep_mode < 0 ? env : g_deep_mode != 0;
         return on && !deep_forced_off() && B <= 2 && c->lv[lvl].L <= 128;
     }
+    int deep_clips() const { return c->cfg.max_batch < 2 ? c->cfg.max_batch : 2; }     // clips per slab: the deep path only runs with B <= 2
     static DeepSrc dsrc(const Tens& t) { return DeepSrc{t.p, t.slab, t.ks, t.C}; }
     static std::string deep_tag(const DeepArgs& a, const DeepTile& t) {
         char tag[96];
@@ -345,7 +346,7 @@ struct Builder {
         out.lvl = lvl_out;
         out.C = a.N;
         out.ks = a.KS;
-        out.slab = (unsigned)((size_t)c->cfg.max_batch * c->lv[lvl_out].L * a.N);
+        out.slab = (unsigned)((size_t)deep_clips() * c->lv[lvl_out].L * a.N);
         // (8 slabs whatever this plan picked: plans of other batch sizes share the buffer and may slice differently)
         out.p = c->buf("act.deep." + name, (size_t)8 * out.slab);
         c->taps[name] = {lvl_out, a.N};
@@ -360,7 +361,11 @@ struct Builder {
             if (!c->bufs.count(key)) {
                 const std::vector<int> tab = deep_rowtab(a, t);
                 float* d = c->buf(key, tab.size());
-                if (d && hipMemcpy(d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) d = nullptr;
+                if (d && hipMemcpy(d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                    c->bufs.erase(key);          // (the zero-filled allocation stays owned by the context; nobody may find it under this key)
+                    c->buf_floats.erase(key);
+                    d = nullptr;
+                }
                 if (!d) { err = "row table upload failed at " + name; return Tens{}; }
             }
             a.rowtab = reinterpret_cast<const int*>(c->bufs[key]);
@@ -748,7 +753,7 @@ struct Builder {
         auto emit_fused = [&](const float* qkv_plain, const Tens& xres) -> Tens {
             Tens out;
             out.lvl = lvl; out.C = C; out.ks = da.nhg;
-            out.slab = (unsigned)((size_t)c->cfg.max_batch * L.L * C);
+            out.slab = (unsigned)((size_t)deep_clips() * L.L * C);
             out.p = c->buf("act.deep." + nm + ".out", (size_t)8 * out.slab);
             if (!out.p) { err = "deep attention allocation failed at " + nm; return Tens{}; }
             c->taps[nm + ".out"] = {lvl, C};
@@ -949,6 +954,10 @@ struct Builder {
             float* W = c->buf("w.out.2.weight", (size_t)9 * cur.C * ld);
             wconv("out.2.weight", f.out_channels, cur.C, 3, 3, false, W, ld);
             float* bias = c->wcopy("out.2.bias", {f.out_channels});
+            // (a geometry whose level 0 is a deep level -- <= 128 tokens at B <= 2 -- ends the last stage on a slab tensor: k_conv
+            //  reads ONE plain tensor and the statistics its producer left)
+            cur = materialize(cur, "head.in");
+            if (!err.empty()) return fail(MTV_ERR_INVALID, err);
             double* site = c->new_site();
             add_stats({cur}, 0, site);
             const Level& L = c->lv[0];
@@ -1167,13 +1176,14 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
         // them.  Whatever order they are met in, each has its own entry: "<key> l" for the one k_lin can run (falling back to a plain
         // "<key>" of an older table), the plain key for the other -- unless that holds a k_lin tile, then "<key> x".
         const bool lin_ok_conv = conv_lin_eligible(a);
+        bool lin_fallback = false;      // the entry found is the plain "<key>" of an older table, possibly the non-k_lin twin's
         auto it = c->tune_cache.end();
         if (lin_ok_conv) {
             char kl[192];
             snprintf(kl, sizeof kl, "%s l", key);
             it = c->tune_cache.find(kl);
-            if (it == c->tune_cache.end()) it = c->tune_cache.find(key);
-            if (it == c->tune_cache.end()) strncpy(key, kl, sizeof key - 1);      // a new measurement goes under the "l" key
+            if (it == c->tune_cache.end()) { it = c->tune_cache.find(key); lin_fallback = it != c->tune_cache.end(); }
+            if (it == c->tune_cache.end()) snprintf(key, sizeof key, "%s", kl);     // a new measurement goes under the "l" key
         } else {
             it = c->tune_cache.find(key);
             if (it != c->tune_cache.end() && it->second.NW == 64) {
@@ -1195,7 +1205,9 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                                    t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1));
             if (!shape_ok || (!tiled_ok && !lin_ok && !b3_ok && !win_ok && !pw_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
                 (!b3_ok && !win_ok && !pw_ok && conv_smem_bytes(a, t) > 120 * 1024)) {
-                c->tune_cache.erase(it);
+                // (a plain entry that a lin-eligible conv only borrowed stays: it may be its twin's; the new measurement goes under "<key> l")
+                if (lin_fallback) { char kl[192]; snprintf(kl, sizeof kl, "%s l", key); snprintf(key, sizeof key, "%s", kl); }
+                else c->tune_cache.erase(it);
                 it = c->tune_cache.end();
             }
         }
@@ -1917,6 +1929,7 @@ int mtv_debug_tap(mtv_ctx* c, const char* name, float* dst, int64_t cap, int* to
             HIPCHK(hipMemcpy(dst, src, (size_t)B * L * C * 4, hipMemcpyDefault));
         } else {
             // a tensor of the deep levels is the sum of its K-slice slabs (deep.hip): added up here in slab order, as its consumers do
+            if (B > 2) B = 2;                              // (a slab holds at most two clips: the deep path only runs with B <= 2)
             const size_t n = (size_t)B * L * C;
             std::vector<float> acc(n), one(n);
             HIPCHK(hipMemcpy(acc.data(), src, n * 4, hipMemcpyDeviceToHost));

@@ -248,6 +248,7 @@ struct mtv_ctx {
         float* p = buf("act." + name, (size_t)cfg.max_batch * lv[lvl].L * C);
         taps[name] = {lvl, C};            // every activation is retrievable by name (mtv_debug_tap)
         bufs["tap." + name] = p;
+        tap_slabs.erase(name);            // (a deep plan built earlier may have registered this name as a slab tensor)
         return p;
     }
     WSlot* slot(const std::string& key, std::vector<int64_t> shape, Role role, float* dst, int ld) {

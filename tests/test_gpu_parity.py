@@ -144,6 +144,10 @@ def test_config3_512px_clip_vs_oracle():
     (16, 8, NARROW_CFG, 1),
     (8, 8, dict(SHALLOW_CFG, use_scale_shift_norm=False), 2), # the h + emb_out branch (unet.py:204-206)
     (24, 8, SHALLOW_CFG, 2),                                  # not powers of two: 60-token deepest level, ragged tiles
+    # level 0 itself is a deep level (128 tokens, B <= 2): the last stage ends on a K-slice slab tensor that the head conv's
+    # GroupNorm + conv must see as ONE plain tensor (head.in is materialised)
+    (8, 4, NARROW_CFG, 1),
+    (8, 4, dict(NARROW_CFG, model_channels=128, num_heads=8), 2),
 ])
 def test_other_geometries_vs_oracle(R, T, cfg, B):
     from oracle import ref_unet

@@ -13,22 +13,23 @@ timeout 120 python tools/profile_ops.py --iters 20 > $O/r${NN}_per_launch_hipeve
 # 3. (the bench line comes after the counter passes: it quotes profiles/pmc_traffic.json, which step 5b refreshes)
 # 4. kernel trace + stats of the same command
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- \
-    python bench.py --steps 100 --warmup 10 --no-cpu-baseline --batched-clips 0 > $O/kt.log 2>&1
+    python bench.py --steps 100 --warmup 10 --no-cpu-baseline --batched-clips 0 --no-res64 > $O/kt.log 2>&1
 KT=$(find $O/kt -name '*kernel_trace.csv' | head -1)
 cp "$(find $O/kt -name '*kernel_stats.csv' | head -1)" $O/r${NN}_rocprofv3_kernel_stats.csv
 python tools/per_op_rocprof.py $O/r${NN}_per_launch_hipevents.txt $KT $O/r${NN}_per_op_rocprof.txt > /dev/null 2>&1
 # 5. PMC passes, each in its own run, kernel trace only (never combined with hip/hsa/sys trace domains), on the MEASURED path: the
 #    hipGraph replay (round 2's image segfaulted there; round 3 found it working again).  A pass that fails or leaves no counter
 #    file is repeated with MTV_EAGER=1 (the same launches as plain launches) and the summary says which one it was.
+BARGS=""      # extra bench.py arguments of the pass (the R = 64 passes set --res 64)
 pmc_pass() {   # $1 = output dir tag, rest = counters
     local tag=$1; shift
     timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$tag -o p -- \
-        python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_$tag.log 2>&1
+        python bench.py $BARGS --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder --no-res64 > $O/pmc_$tag.log 2>&1
     local rc=$?
     if [ $rc -ne 0 ] || [ -z "$(find $O/pmc_$tag -name '*counter_collection.csv' | head -1)" ]; then
         echo "pmc $tag on the graph path: rc=$rc -> eager"; rm -rf $O/pmc_$tag
         MTV_EAGER=1 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$tag -o p -- \
-            python bench.py --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder > $O/pmc_$tag.log 2>&1
+            python bench.py $BARGS --steps 30 --warmup 8 --no-cpu-baseline --batched-clips 0 --no-autoencoder --no-res64 > $O/pmc_$tag.log 2>&1
         echo "$tag eager" >> $O/pmc_modes.txt
     else
         echo "$tag graph" >> $O/pmc_modes.txt
@@ -50,8 +51,24 @@ python tools/update_pmc_traffic.py $O/pmc_util.json "round $NN (tools/make_profi
 # 3. the bench line (N=1, with cpu_baseline and batched_info), quoting the counters just collected
 timeout 500 python bench.py --steps 250 --warmup 25 > $O/r${NN}_bench_n1.json 2>$O/bench.err
 rm -rf $O/pmc_SQ
-# 6. configs[3] (R=64), informational
+# 6. configs[3] (R=64), informational -- with its OWN counter passes (profiles/pmc_traffic.json is keyed by workload: "R64")
 timeout 300 python bench.py --res 64 --steps 40 --warmup 10 --no-cpu-baseline --batched-clips 0 > /dev/null 2>&1
+if [ -z "$MTV_PROFILES_SKIP_R64_PMC" ]; then
+    BARGS="--res 64"
+    timeout 200 python tools/profile_ops.py --res 64 --iters 10 > $O/r${NN}_per_launch_hipevents_res64.txt 2>>$O/ops.err
+    NL6=$(grep -m1 -oE '^# [0-9]+ launches' $O/r${NN}_per_launch_hipevents_res64.txt | grep -oE '[0-9]+')
+    timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt64 -o kt -- \
+        python bench.py --res 64 --steps 40 --warmup 10 --no-cpu-baseline --batched-clips 0 > $O/kt64.log 2>&1
+    KT6=$(find $O/kt64 -name '*kernel_trace.csv' | head -1)
+    for c in FETCH_SIZE WRITE_SIZE; do pmc_pass ${c}_r64 $c; done
+    pmc_pass SQ_r64 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE
+    python tools/pmc_util.py "$(find $O/pmc_SQ_r64 -name '*counter_collection.csv' | head -1)" --launches $NL6 \
+        --fetch "$(find $O/pmc_FETCH_SIZE_r64 -name '*counter_collection.csv' | head -1)" --write "$(find $O/pmc_WRITE_SIZE_r64 -name '*counter_collection.csv' | head -1)" \
+        --trace $KT6 --json $O/pmc_util_r64.json > $O/r${NN}_pmc_util_res64.txt 2>&1
+    python tools/update_pmc_traffic.py $O/pmc_util_r64.json "round $NN (tools/make_profiles.sh)" "$(git rev-parse --short HEAD 2>/dev/null)" R64; cp profiles/pmc_traffic.json $O/pmc_traffic.json
+    rm -rf $O/kt64 $O/pmc_SQ_r64 $O/pmc_FETCH_SIZE_r64 $O/pmc_WRITE_SIZE_r64
+    BARGS=""
+fi
 # (with the CPU leg: BASELINE.md section 3 asks for >= 3 timed steps of the oracle at this geometry; bench.py stops it after 60 s)
 timeout 600 python bench.py --res 64 --steps 150 --warmup 15 --batched-clips 0 > $O/r${NN}_bench_res64_n1.json 2>/dev/null
 # 7. the autoencoder steps either side of the loop (informational): per-launch tables + rocprofv3 kernel stats of decode

@@ -36,9 +36,15 @@ if b:
         print(f"| family `{k}` | {v['ms_per_step']} ms per step, {v['launches']} launches" + (f", {v['tflops']} TFLOP/s" if v.get("tflops") else "") +
               (f", {v['algorithmic_GBs']} GB/s algorithmic" if v.get("algorithmic_GBs") else "") + " |")
     if c:
-        ph = c.get("physical_cores_rule") or {}
-        print(f"| `cpu_baseline` | {c['value']} steps/s at {c['cores']} threads ({c['sample'][:80]}...); physical-core rule: {ph.get('value')} steps/s at {ph.get('threads')} threads ({ph.get('steps')} steps) |")
+        bt = c.get("best_threads") or {}
+        print(f"| `cpu_baseline` | {c['value']} steps/s at {c['cores']} threads = physical cores ({c['sample'][:60]}...); best of the thread probe: {bt.get('value')} steps/s at {bt.get('threads')} threads ({bt.get('steps')} steps) |")
     print(f"| `gpu_active_s` | {b.get('gpu_active_s')} |")
+    hv = (r.get("hbm_view") or {}).get("deep_levels")
+    if hv:
+        print(f"| `roofline.hbm_view.deep_levels` | {hv['achieved_GBs']} GB/s algorithmic = **{hv['frac']}** of 8 TB/s over {hv['launches']} k_deep_conv launches ({hv['ms_per_step']} ms per step) |")
+    r6 = b.get("res64_info")
+    if r6:
+        print(f"| `res64_info` (configs[3], informational) | {r6['steps_per_s']} steps/s, {r6['ms_per_step']} ms per step; conv {r6['conv_frac_of_f32_mfma_peak']} / attention {r6['attention_frac_of_f32_mfma_peak']} of the f32-MFMA peak |")
     bi, ai = b.get("batched_info"), b.get("autoencoder_info")
     if bi:
         print(f"| 8 clips batched (informational) | {bi['clip_steps_per_s']} clip-steps/s, conv {bi['k_conv_frac_of_f32_mfma_peak']} / attention {bi['k_attention_frac_of_f32_mfma_peak']} of the f32-MFMA peak |")
