@@ -31,7 +31,40 @@ def ddconfig(res):
                 num_res_blocks=2, attn_resolutions=[], splits=1)
 
 
+def composed_s250():
+    """--from-base-s250: BASELINE configs[4] composed at the metric's own schedule.  The reference's OWN 250-step sample
+    (tests/golden/base.npz `sample_S250`, written by make_golden.py from the imported reference DDPM + UNet) is decoded by the
+    reference's own ViTAutoencoder.decode_from_sample (256x256, recipe weights seed 22) exactly as sample.py:377-387 does
+    (clamp, (1 + x) * 127.5, uint8) -> tests/golden/composed_s250.npz.  The GPU test runs HIP sampler (S = 250) -> HIP decode."""
+    torch.set_num_threads(os.cpu_count() or 8)
+    from einops import rearrange
+    from models.autoencoder.autoencoder_vit import ViTAutoencoder
+    base = np.load(os.path.join(HERE, "base.npz"))
+    z = torch.from_numpy(base["sample_S250"])
+    ae = ViTAutoencoder(4, ddconfig(256)).eval()
+    filler.fill_autoencoder_(ae, seed=22)
+    sd = {k: v.clone() for k, v in ae.state_dict().items()}
+    with torch.no_grad():
+        fake = ae.decode_from_sample(z).clamp(-1, 1).cpu()                       # sample.py:386
+    d = float((ref_ae.decode_from_sample(sd, z, 256, 16).clamp(-1, 1) - fake).abs().max())
+    print(f"composed S=250: frames std {float(fake.std()):.3f}, |frames| max {float(fake.abs().max()):.3f}; oracle decode vs reference {d:.3e}")
+    assert d <= 2e-5, d
+    f255 = (1 + rearrange(fake, "(b t) c h w -> b t h w c", b=1)) * 127.5        # sample.py:387
+    u8 = f255.type(torch.uint8)                                                  # sample.py:402 (as stored)
+    sub = 5
+    np.savez_compressed(os.path.join(HERE, "composed_s250.npz"), ae_seed=np.int64(22), unet_seed=np.int64(int(base["seed"])),
+                        frames_sub5=fake[:, :, ::sub, ::sub].contiguous().numpy(), frames_mean_per_frame=fake.mean(dim=(1, 2, 3)).numpy(),
+                        frames_abs_sum=np.float64(fake.double().abs().sum()), u8_sub5=u8[0, :, ::sub, ::sub].contiguous().numpy(),
+                        u8_sum=np.int64(int(u8.to(torch.int64).sum())))
+    print("composed_s250.npz written")
+    with open(os.path.join(HERE, "PIN_REPORT.txt"), "a") as f:
+        f.write("# composed configs[4] at S = 250: reference sample_S250 -> reference decode_from_sample (make_golden_ae.py --from-base-s250)\n")
+        f.write(f"{'oracle decode of the reference S=250 sample':44s} {d:.3e}\n")
+
+
 def main():
+    if "--from-base-s250" in sys.argv[1:]:
+        return composed_s250()
     torch.set_num_threads(os.cpu_count() or 8)
     from models.autoencoder.autoencoder_vit import ViTAutoencoder
     out, report = {}, []

@@ -182,6 +182,36 @@ def test_config4_full_size_sampler_then_decode_vs_oracle():
     assert mse <= 1e-8 and float((frames - fr).abs().max()) <= TOL, (mse, float((frames - fr).abs().max()))
 
 
+def test_config4_composed_at_250_steps_vs_reference_golden():
+    """BASELINE configs[4] composed at the metric's own schedule against the REFERENCE: HIP sampler (S = 250, the base golden's
+    weights / inputs / noise) -> HIP decode_from_sample (256x256) -> clamp -> 8-bit frames, against tests/golden/composed_s250.npz =
+    the reference's own 250-step sample decoded by the reference's own autoencoder (make_golden_ae.py --from-base-s250;
+    sample.py:377-387,402).  Frames max-abs <= 1e-3, stored 8-bit frames within 1 count."""
+    from conftest import BASE_CFG
+    from moditalker_amd.pipeline import frames_to_uint8
+    g = np.load(os.path.join(GOLDEN, "composed_s250.npz"))
+    dev = _dev()
+    R, T, S = 32, 16, 250
+    L = R * R + 2 * T * R
+    net = DiffusionWrapper(UNetModel(**BASE_CFG, frames=T, max_batch=1)).eval()
+    filler.fill_module_(net, seed=int(g["unet_seed"]), skip_prefixes=("output_bg_",))
+    net = net.to(dev)
+    ae = _ae(256, int(g["ae_seed"]))
+    x, cond, ic = filler.synthetic_inputs(1, R, T, seed=7, tag="base")
+    noise = [z.to(dev) for z in filler.noise_list(S, (1, 4, L), seed=7, tag=f"base.S{S}")]
+    dm = DDPM(net, channels=4, image_size=R, sampling_timesteps=S, w=0.0).to(dev)
+    z = dm.sample(batch_size=1, cond=cond.to(dev), image_cond=ic.to(dev), noise=noise)
+    fake = ae.decode_from_sample(z).clamp(-1, 1).cpu()
+    assert fake.shape == (16, 3, 256, 256)
+    d = float((fake[:, :, ::5, ::5] - torch.from_numpy(g["frames_sub5"])).abs().max())
+    assert d <= TOL, d
+    assert float((fake.mean(dim=(1, 2, 3)) - torch.from_numpy(g["frames_mean_per_frame"])).abs().max()) <= 1e-4
+    u8 = frames_to_uint8((1 + fake.permute(0, 2, 3, 1)[None]) * 127.5)[0]          # [T, H, W, 3], as sample.py:387,402 stores them
+    du = np.abs(u8[:, ::5, ::5].astype(np.int32) - g["u8_sub5"].astype(np.int32))
+    assert du.max() <= 1, int(du.max())
+    assert abs(int(u8.astype(np.int64).sum()) - int(g["u8_sum"])) <= 1e-4 * int(g["u8_sum"])
+
+
 def test_config4_full_size_through_conditioning_vs_oracle(tmp_path):
     """BASELINE configs[4] end to end at its own geometry, starting from the files the pipeline starts from: aligned landmark
     .npy files -> landmarks_to_images (cv2.circle restated) -> the four 256x256 extracts of sample.py:328-331 (RGB autoencoder

@@ -127,6 +127,23 @@ def test_autoencoder_oracle_vs_reference_golden(tag, res, B, sub):
     assert float((z - torch.from_numpy(g[f"{tag}_extract"])).abs().max()) <= TOL
 
 
+def test_composed_s250_oracle_decode_of_reference_sample_vs_reference_golden():
+    """The composed configs[4] fixture (make_golden_ae.py --from-base-s250): the oracle's decode of the reference's own 250-step
+    sample reproduces the reference autoencoder's frames -- the CPU-side pin of what the GPU test composes."""
+    from oracle import ref_ae
+    g = np.load(os.path.join(GOLDEN, "composed_s250.npz"))
+    ga = np.load(os.path.join(GOLDEN, "ae.npz"))
+    seed = int(g["ae_seed"])
+    sd = _ae_state_dict(ga, seed)
+    for k in ("xt_pos_embedding", "yt_pos_embedding"):
+        sd[k] = filler.fill_tensor(k, (1, 256 // 8 + 1, 384), seed)
+    z = torch.from_numpy(np.load(os.path.join(GOLDEN, "base.npz"))["sample_S250"])
+    fake = ref_ae.decode_from_sample(sd, z, 256, 16).clamp(-1, 1)
+    assert float((fake[:, :, ::5, ::5] - torch.from_numpy(g["frames_sub5"])).abs().max()) <= TOL
+    u8 = ((1 + fake.permute(0, 2, 3, 1)) * 127.5).to(torch.uint8).numpy()
+    assert np.abs(u8[:, ::5, ::5].astype(np.int32) - g["u8_sub5"].astype(np.int32)).max() <= 1
+
+
 def test_cross_attention_oracle_vs_reference_golden():
     from oracle import ref_xattn
     g = np.load(os.path.join(GOLDEN, "xattn.npz"))
