@@ -207,6 +207,8 @@ def main():
             key = p["name"].split(":")[0]
             if key == "attn" and "+proj" in p["name"]:
                 key = "attnproj"                   # k_deep_attn: attention core + proj_out of a deep level in one launch (csrc/deep.hip)
+            if key == "attn" and " blk " in p["name"]:
+                key = "attnblock"                  # k_deep_block: GroupNorm -> qkv -> attention -> proj_out of a deep level in one launch (csrc/block.hip)
             f = fam.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             f["ms"] += p["ms"]
             f["flops"] += p["flops"]

@@ -182,11 +182,17 @@ int mtv_debug_deep(int mode);
  *   MTV_DEEP_OPT_SLICED_QKV     the attention blocks' qkv conv K-sliced on k_deep_conv (+ a finalize pass) instead of k_conv;
  *   MTV_DEEP_OPT_UNSLICED_QKV   ... on k_deep_conv with the whole K per workgroup (plain output) where it fits in LDS;
  *   MTV_DEEP_OPT_NO_FUSED_ATTN  k_attention + a proj_out conv instead of the fused k_deep_attn;
- * -1 = back to the defaults / the MTV_DEEP_INLAUNCH, MTV_DEEP_QKV, MTV_DEEP_QKV1, MTV_DEEP_NO_ATTN environment variables. */
+ *   MTV_DEEP_OPT_NO_BLOCK       the three-launch attention block of round 4 (k_deep_finalize + qkv conv + k_deep_attn) instead of the
+ *                               one-launch k_deep_block (csrc/block.hip: GroupNorm -> qkv -> attention -> proj_out in one kernel, a
+ *                               cluster of workgroups per head, two in-launch hand-offs); the four bits above imply it where they
+ *                               change the block's dataflow (they describe the three-launch form);
+ * -1 = back to the defaults / the MTV_DEEP_INLAUNCH, MTV_DEEP_QKV, MTV_DEEP_QKV1, MTV_DEEP_NO_ATTN, MTV_DEEP_NO_BLOCK environment
+ * variables. */
 #define MTV_DEEP_OPT_INLAUNCH 1
 #define MTV_DEEP_OPT_SLICED_QKV 2
 #define MTV_DEEP_OPT_UNSLICED_QKV 4
 #define MTV_DEEP_OPT_NO_FUSED_ATTN 8
+#define MTV_DEEP_OPT_NO_BLOCK 16
 int mtv_debug_deep_options(int mask);
 
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */

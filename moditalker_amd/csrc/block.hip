@@ -1,0 +1,626 @@
+// One attention block of the DEEP levels (<= 128 tokens per clip) in ONE launch, for gfx950:
+//     GroupNorm -> qkv 1x1 conv -> QKVAttentionLegacy -> proj_out 1x1 conv + residual
+// (MToV/models/ddpm/unet.py:210-300 AttentionBlock / AttentionBlock1D, :303-326 QKVAttentionLegacy; GroupNorm32
+// diffusionmodules.py:156-173), replacing the three launches k_deep_finalize (slabs -> plain input + statistics), k_conv
+// (qkv) and k_deep_attn (core + proj_out) of deep.hip, round 4: 18 x 3 launches of 4.6 + 7.7-11.4 + 8.8-15.3 us per DDIM step.
+//
+// Every block boundary inside the block is an all-to-all dependency (the qkv conv reads all channels, a head reads all tokens,
+// proj_out reads all heads), which is why round 4 paid one kernel boundary + one cold start per dependency.  Here the block is
+// cut along HEADS instead: a CLUSTER of CL workgroups owns one (clip, head) and nothing but the block's input and output ever
+// crosses clusters --
+//   stage 1  workgroup j of the cluster takes K slice j (CS = C / CL channels, whole GroupNorm groups) of the head's qkv GEMM:
+//            stages ALL tokens of its channel slice (adding the input's K-slice slabs in slab order, as every consumer of the
+//            deep levels does), computes the GroupNorm statistics of its groups itself (per plane, or over all planes for
+//            AttentionBlock1D), normalises once, multiplies by W_qkv[head's 3d rows][slice] -> partial [L x 3d]   -> scratch
+//   hand-off 1 (cluster-wide arrival counter)
+//   stage 2  workgroup j adds the CL partials of ITS rows (slice order: run-to-run bit-equal) + bias -> the head's q | k | v rows
+//   hand-off 2
+//   stage 3  workgroup j = (query tile, column part): K rows, V^T and its 16 queries to LDS, S^T = K Q^T per key tile (a query is
+//            a lane column, as k_attention / k_deep_attn), softmax, O^T += V^T P^T, key tiles merged through LDS; then
+//            [16 x cols] = attention rows x W_proj[cols][head's d columns]; the HEAD is the K slice of the projection: the
+//            partial result goes to output slab `head` (slab h also carries input slab h as the residual, slab 0 the bias).
+// The output is a deep tensor of H slabs: its consumers add them up (deep.hip).
+//
+// Hand-offs inside the launch follow cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "valid forms": payload by
+// 8-byte agent-scope (sc1, write-through) atomic stores, every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier,
+// ONE lane takes the cluster's ticket (relaxed agent atomic add on a 64-bit monotonic counter: no reset, no ABA), polls it with
+// relaxed agent loads + s_sleep, workgroup barrier, payload read back with 8-byte agent-scope atomic loads (L1-bypassing) --
+// correct under any workgroup -> XCD placement.  All workgroups of the launch must be resident together: the grid is B x H x CL
+// <= 128 workgroups of 512 threads (one per CU on half the chip).  A wait that exceeds ~20 ms raises *fault and falls through
+// (garbage, never a hang); the host checks the flag (mtv_last_error: "in-launch hand-off timed out").
+#include <cstdio>
+#include <cstdlib>
+
+#include "mtv_internal.h"
+
+namespace mtv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BLK_NTH = 512;
+constexpr int BLK_MAX_NG = 32;        // GroupNorm groups per channel slice
+constexpr unsigned long long BLK_WAIT_TICKS = 2000000ull;     // s_memtime ticks (100 MHz): 20 ms
+
+typedef __attribute__((address_space(1))) unsigned long long blk_gu64;
+
+__device__ __forceinline__ int blk_usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ void blk_park_quad(float* dst, const f32x4& v) {          // write-through (sc1) 8-byte stores
+    blk_gu64* d = (blk_gu64*)(unsigned long long)dst;
+    __hip_atomic_store(d, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 blk_fetch_quad(const float* src) {                   // L1-bypassing (sc1) 8-byte loads
+    const blk_gu64* s = (const blk_gu64*)(unsigned long long)src;
+    const unsigned long long t0 = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t1 = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__uint_as_float((unsigned)t0), __uint_as_float((unsigned)(t0 >> 32)), __uint_as_float((unsigned)t1), __uint_as_float((unsigned)(t1 >> 32))};
+}
+
+// Cluster-wide hand-off: every workgroup of the cluster has parked its payload (all threads call this).  The counter only ever
+// grows: arrival n belongs to round n / CL, the round is complete when the counter reaches (n / CL + 1) CL.
+__device__ __forceinline__ void blk_handoff(unsigned long long* cnt, int cl_shift, int* fault, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = ((old >> cl_shift) + 1ull) << cl_shift;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memtime() - t0 > BLK_WAIT_TICKS) {
+                __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (host-mapped word: a plain store, no PCIe atomic)
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float blk_swap_max16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float blk_swap_max32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+}  // namespace
+
+#ifdef MTV_DEEP_STAMP   // s_memtime of lane 0 of wave 0 of workgroups 0 and gridDim / 2: [wg][16 slots]
+#define BLK_STAMP(k) do { if (a.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) \
+                               a.dbg[(blockIdx.x ? 16 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BLK_STAMP(k) do { } while (0)
+#endif
+
+// LDS plan (floats), shared by host sizing and the kernel
+struct BlkLds {
+    int LP;                 // token rows padded to a multiple of 16
+    int XS, WS;             // row strides of the staged input slice / qkv weight slice
+    int xs, wt, stat, img;  // stage 1: input slice [LP][XS] | weights [3D][WS] | statistics (doubles) | result image [LP][3D + 4] (aliases xs / wt)
+    int ks, vt, qs, att, os, ml, po;   // stage 3: K rows [kcap][D + 4] | V^T [D][kcap + 4] | Q [16][D + 4] | attention rows [16][D + 8] |
+                                       // key-tile partials [8][16][D + 4] | (m, l) [8][16][2] | proj image [16][ncols + 4]
+    int total;
+};
+__host__ __device__ inline BlkLds blk_lds(int L, int D, int CS, int ncols) {
+    BlkLds p;
+    p.LP = (L + 15) / 16 * 16;
+    p.XS = CS + 8;
+    p.WS = CS + 4;
+    const int NQ = 3 * D;
+    p.xs = 0;
+    p.wt = p.xs + p.LP * p.XS;
+    int s1 = p.wt + NQ * p.WS;
+    s1 = (s1 + 3) & ~3;
+    p.stat = s1;
+    s1 += 3 * BLK_MAX_NG * 2 * 2;
+    p.img = 0;
+    const int img_end = p.LP * (NQ + 4);
+    const int st1 = s1 > img_end ? s1 : img_end;        // (the image overwrites slice + weights after the GEMM; statistics are dead by then too)
+    const int kcap = p.LP;
+    p.ks = 0;
+    p.vt = p.ks + kcap * (D + 4);
+    p.qs = p.vt + D * (kcap + 4);
+    p.att = p.qs + 16 * (D + 4);
+    p.os = p.att + 16 * (D + 8);
+    p.ml = p.os + 8 * 16 * (D + 4);
+    p.po = p.ml + 8 * 16 * 2;
+    const int st3 = p.po + 16 * (ncols + 4);
+    p.total = st1 > st3 ? st1 : st3;
+    return p;
+}
+
+template <int D>
+__global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
+    const int tid = threadIdx.x;
+    BLK_STAMP(0);
+    touch_kernargs<(int)sizeof(DeepBlockArgs)>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr float LOG2E = 1.4426950408889634f;
+    constexpr int NQ = 3 * D, NDT = D / 16, QPR = D / 4, KSTR = D + 4, AS = D + 8;
+    constexpr int PT = 2;                                   // proj column tiles per wave (ncols <= 256)
+    const int lane = tid & 63;
+    const int wave = blk_usgpr(tid >> 6);
+    const int jl = lane & 15, g = lane >> 4;
+    const int blk = blk_usgpr((int)blockIdx.x);
+    const int CL = a.CL, CS = a.CS, L = a.L, C = a.C, H = a.H;
+    const int j = blk & (CL - 1);                           // K slice / row share / stage-3 item of this workgroup
+    const int bh = blk >> a.cl_shift;
+    const int b = blk_usgpr(bh / H), h = blk_usgpr(bh - (bh / H) * H);
+    const int b1 = a.r * a.r, b2 = b1 + a.t * a.r;
+    const BlkLds lp = blk_lds(L, D, CS, a.ncols);
+    const int LP = lp.LP, XS = lp.XS, WS = lp.WS;
+    float* const xs = smem + lp.xs;
+    float* const wt = smem + lp.wt;
+    double* const sdp = reinterpret_cast<double*>(smem + lp.stat);       // [3 planes][BLK_MAX_NG][2]
+    const int cs0 = j * CS;
+    const int qw_shift = a.qw_shift, QW = 1 << qw_shift;                 // quads per row of the slice
+    const int qd = tid & (QW - 1), rl = tid >> qw_shift, RP = BLK_NTH >> qw_shift;
+    unsigned long long* const cnt = a.cnt + (size_t)bh * 2;
+
+    // =========================================================================================================== stage 1
+    // request order: input slice (first pass; L2 / Infinity-Cache warm) -> qkv weight slice -> proj fragments (HBM-cold, needed
+    // last): a wave's loads return in order
+    const int xks = a.x.ks;
+    const float* const xcol = a.x.p + (size_t)b * L * a.x.C + cs0 + 4 * qd;
+    f32x4 xv[8];
+    {
+        const int row = rl < L ? rl : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const f32x4*>(xcol + (size_t)row * a.x.C + (size_t)(k < xks ? k : 0) * a.x.slab_stride);
+    }
+    constexpr int WU = (NQ * 16 + BLK_NTH - 1) / BLK_NTH;                // weight quads per thread at CS = 64
+    f32x4 wreg[WU];
+    {
+        const float* wb = a.Wq + (size_t)(h * NQ) * C + cs0;
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int e = tid + BLK_NTH * u;
+            const int n = e >> qw_shift, wq = e & (QW - 1);
+            wreg[u] = *reinterpret_cast<const f32x4*>(wb + (size_t)(n < NQ ? n : 0) * C + 4 * wq);
+        }
+    }
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + cs0 + 4 * qd);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(a.beta + cs0 + 4 * qd);
+    // proj_out fragments of this workgroup's stage-3 item (when it has exactly one: the usual case): B operand straight from the
+    // checkpoint layout [n][k]: lane (jl, g) holds Wp[n0 + 16 ct + jl][h D + 16 cc + 4 g .. + 3]
+    const int nitems = a.nqt * a.ncp;
+    const int nct2 = a.ncols >> 4;
+    f32x4 wp[PT][NDT];
+    auto load_wp = [&](int cp) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int ct = wave + 8 * pt;
+            const int n = cp * a.ncols + 16 * (ct < nct2 ? ct : 0) + jl;
+#pragma unroll
+            for (int cc = 0; cc < NDT; ++cc) wp[pt][cc] = *reinterpret_cast<const f32x4*>(a.Wp + (size_t)n * C + h * D + 16 * cc + 4 * g);
+        }
+    };
+    if (j < nitems) load_wp(j / a.nqt);
+    BLK_STAMP(1);
+    for (int e = tid; e < 3 * BLK_MAX_NG * 2; e += BLK_NTH) sdp[e] = 0.0;
+    __syncthreads();
+    // input slice -> LDS (slab order), statistics per (plane, group) of the slice
+    const int gs = a.gs;
+    {
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const bool wide = (gs & 3) == 0;                                  // a quad lies inside one group
+        auto consume = [&](int row, const f32x4& x) {
+            *reinterpret_cast<f32x4*>(xs + row * XS + 4 * qd) = x;
+            if (row >= L) return;
+            const int p = row >= b2 ? 2 : (row >= b1 ? 1 : 0);
+            if (wide) {
+                const double s = ((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3]);
+                const double ss = ((double)x[0] * x[0] + (double)x[1] * x[1]) + ((double)x[2] * x[2] + (double)x[3] * x[3]);
+                acc[0] += p == 0 ? s : 0.0; acc[1] += p == 0 ? ss : 0.0;
+                acc[2] += p == 1 ? s : 0.0; acc[3] += p == 1 ? ss : 0.0;
+                acc[4] += p == 2 ? s : 0.0; acc[5] += p == 2 ? ss : 0.0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                              // (narrow test models only: groups of 1 or 2 channels)
+                    const int gi = (4 * qd + k) / gs;
+                    atomicAdd(&sdp[(p * BLK_MAX_NG + gi) * 2], (double)x[k]);
+                    atomicAdd(&sdp[(p * BLK_MAX_NG + gi) * 2 + 1], (double)x[k] * x[k]);
+                }
+            }
+        };
+        {
+            f32x4 x = xv[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                if (k < xks) x += xv[k];                                   // slab order
+            if (rl < LP) consume(rl, rl < L ? x : f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        for (int row = rl + RP; row < LP; row += RP) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (row < L) {
+                f32x4 t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(xcol + (size_t)row * a.x.C + (size_t)(k < xks ? k : 0) * a.x.slab_stride);
+                x = t[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k)
+                    if (k < xks) x += t[k];
+            }
+            consume(row, x);
+        }
+        if (wide) {
+            const int gi = (4 * qd) / gs;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                if (acc[2 * p + 1] != 0.0) {
+                    atomicAdd(&sdp[(p * BLK_MAX_NG + gi) * 2], acc[2 * p]);
+                    atomicAdd(&sdp[(p * BLK_MAX_NG + gi) * 2 + 1], acc[2 * p + 1]);
+                }
+        }
+    }
+    // qkv weight slice -> LDS [n][k] (a straight copy of the checkpoint's rows)
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+        const int e = tid + BLK_NTH * u;
+        const int n = e >> qw_shift, wq = e & (QW - 1);
+        if (n < NQ) *reinterpret_cast<f32x4*>(wt + n * WS + 4 * wq) = wreg[u];
+    }
+    BLK_STAMP(2);
+    __syncthreads();
+    // normalise in place: y = (x - mean) rstd gamma + beta, statistics per plane or over all planes (whole)
+    {
+        int cur_p = -1;
+        f32x4 A = {0.f, 0.f, 0.f, 0.f}, Bc = A;
+        for (int row = rl; row < L; row += RP) {
+            const int p = row >= b2 ? 2 : (row >= b1 ? 1 : 0);
+            if (p != cur_p) {
+                cur_p = p;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int gi = (4 * qd + k) / gs;
+                    double sx, sy;
+                    if (a.whole) {
+                        sx = (sdp[(0 * BLK_MAX_NG + gi) * 2] + sdp[(1 * BLK_MAX_NG + gi) * 2]) + sdp[(2 * BLK_MAX_NG + gi) * 2];
+                        sy = (sdp[(0 * BLK_MAX_NG + gi) * 2 + 1] + sdp[(1 * BLK_MAX_NG + gi) * 2 + 1]) + sdp[(2 * BLK_MAX_NG + gi) * 2 + 1];
+                    } else {
+                        sx = sdp[(p * BLK_MAX_NG + gi) * 2];
+                        sy = sdp[(p * BLK_MAX_NG + gi) * 2 + 1];
+                    }
+                    const double inv_n = a.whole ? a.inv_n[3] : a.inv_n[p];
+                    const double mean = sx * inv_n;
+                    double var = sy * inv_n - mean * mean;
+                    var = var < 0.0 ? 0.0 : var;
+                    const float mu = (float)mean, rstd = 1.0f / sqrtf((float)var + 1e-5f);
+                    const float sc = rstd * ga[k];
+                    A[k] = sc;
+                    Bc[k] = be[k] - sc * mu;
+                }
+            }
+            f32x4* cell = reinterpret_cast<f32x4*>(xs + row * XS + 4 * qd);
+            f32x4 v = *cell;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], A[k], Bc[k]);
+            *cell = v;
+        }
+    }
+    __syncthreads();
+    BLK_STAMP(3);
+    // partial qkv of this K slice: [LP x NQ] = xs [LP x CS] . wt^T; tiles (row tile, column tile) dealt round-robin to the waves
+    const int nrt = LP >> 4;
+    constexpr int NCT = NQ / 16;
+    constexpr int MAXT = (8 * NCT + 7) / 8;                              // tiles per wave at 128 tokens
+    f32x4 tacc[MAXT];
+    {
+        const int ntile = nrt * NCT, nchunk = CS >> 4;
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            tacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int tl = wave + 8 * u;
+            if (tl < ntile) {
+                const int rt = tl / NCT, ct = tl - rt * NCT;
+                for (int cc = 0; cc < nchunk; ++cc) {
+                    const f32x4 af = *reinterpret_cast<const f32x4*>(xs + (16 * rt + jl) * XS + 16 * cc + 4 * g);
+                    const f32x4 bf = *reinterpret_cast<const f32x4*>(wt + (16 * ct + jl) * WS + 16 * cc + 4 * g);
+#pragma unroll
+                    for (int sI = 0; sI < 4; ++sI) tacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[sI], bf[sI], tacc[u], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                                  // slice and weights are dead: the image takes their place
+        float* const img = smem + lp.img;
+        constexpr int IS = NQ + 4;
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int tl = wave + 8 * u;
+            if (tl < ntile) {
+                const int rt = tl / NCT, ct = tl - rt * NCT;
+                // D lane (col jl, group g) reg rr = row 4 g + rr
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) img[(16 * rt + 4 * g + rr) * IS + 16 * ct + jl] = tacc[u][rr];
+            }
+        }
+        __syncthreads();
+        float* const part = a.part + ((size_t)bh * CL + j) * L * NQ;
+        for (int e = tid; e < L * (NQ / 4); e += BLK_NTH) {
+            const int row = e / (NQ / 4), q4 = e - row * (NQ / 4);
+            blk_park_quad(part + (size_t)row * NQ + 4 * q4, *reinterpret_cast<const f32x4*>(img + row * IS + 4 * q4));
+        }
+    }
+    BLK_STAMP(4);
+    blk_handoff(cnt, a.cl_shift, a.fault, tid);
+    BLK_STAMP(5);
+    // =========================================================================================================== stage 2
+    // this workgroup's rows of the head's q | k | v: the CL partials in slice order + bias
+    {
+        const int rows_per = a.rows_per, row0 = j * rows_per;
+        const float* const pbase = a.part + (size_t)bh * CL * L * NQ;
+        float* const qkv = a.qkv + (size_t)bh * L * NQ;
+        for (int e = tid; e < rows_per * (NQ / 4); e += BLK_NTH) {
+            const int rr = e / (NQ / 4), q4 = e - rr * (NQ / 4);
+            const int row = row0 + rr;
+            if (row >= L) continue;
+            f32x4 t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = blk_fetch_quad(pbase + ((size_t)(k < CL ? k : 0) * L + row) * NQ + 4 * q4);
+            f32x4 v = t[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k)
+                if (k < CL) v += t[k];                                     // slice order
+            v += *reinterpret_cast<const f32x4*>(a.bq + h * NQ + 4 * q4);
+            blk_park_quad(qkv + (size_t)row * NQ + 4 * q4, v);
+        }
+    }
+    BLK_STAMP(6);
+    blk_handoff(cnt + 1, a.cl_shift, a.fault, tid);
+    BLK_STAMP(7);
+    // =========================================================================================================== stage 3
+    float* const Ks = smem + lp.ks;
+    float* const Vt = smem + lp.vt;
+    float* const Qs = smem + lp.qs;
+    float* const Att = smem + lp.att;
+    float* const Os = smem + lp.os;
+    float* const ml = smem + lp.ml;
+    float* const po = smem + lp.po;
+    const int VSTR = LP + 4, POS = a.ncols + 4;
+    const float* const qkvh = a.qkv + (size_t)bh * L * NQ;
+    for (int it = j; it < nitems; it += CL) {
+        const int qt = it % a.nqt, cp = it / a.nqt;
+        const int q0 = 16 * qt;
+        if (it != j) load_wp(cp);
+        // keys this query tile can see: all (whole) or the planes its queries live in
+        int k0 = 0, k1 = L;
+        if (!a.whole) {
+            const int qlast = (q0 + 16 < L ? q0 + 16 : L) - 1;
+            k0 = q0 >= b2 ? b2 : (q0 >= b1 ? b1 : 0);
+            k1 = qlast >= b2 ? L : (qlast >= b1 ? b2 : b1);
+        }
+        const int nk = k1 - k0, nkt = (nk + 15) >> 4;
+        // residual share of this head: input slabs h, h + H, ... of this tile's rows / columns (requested now, used in the epilogue)
+        const int nq4 = a.ncols >> 2;
+        constexpr int RU = 2;                                              // 16 x 256 / 4 = 1024 quads / 512 threads
+        f32x4 rres[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            rres[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int e = tid + BLK_NTH * u;
+            const int rr = e / nq4, cq = e - rr * nq4;
+            const int tok = q0 + rr;
+            if (e < 16 * nq4 && tok < L && h < xks)
+                rres[u] = *reinterpret_cast<const f32x4*>(a.x.p + (size_t)h * a.x.slab_stride + ((size_t)b * L + tok) * a.x.C + cp * a.ncols + 4 * cq);
+        }
+        // K rows (x d^-1/4), V^T, Q (x d^-1/4 log2 e: scores in the log2 domain) -> LDS
+        for (int e = tid; e < nkt * 16 * QPR; e += BLK_NTH) {
+            const int key = e / QPR, kq = e - key * QPR;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (key < nk) {
+                const float* p = qkvh + (size_t)(k0 + key) * NQ + D + 4 * kq;
+                kv = blk_fetch_quad(p) * a.scale;
+                vv = blk_fetch_quad(p + D);
+            }
+            *reinterpret_cast<f32x4*>(Ks + key * KSTR + 4 * kq) = kv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Vt[(4 * kq + c) * VSTR + key] = vv[c];
+        }
+        if (tid < 16 * QPR) {
+            const int qr = tid / QPR, kq = tid - qr * QPR;
+            const int tok = q0 + qr;
+            f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+            if (tok < L) qv = blk_fetch_quad(qkvh + (size_t)tok * NQ + 4 * kq) * (a.scale * LOG2E);
+            *reinterpret_cast<f32x4*>(Qs + qr * KSTR + 4 * kq) = qv;
+        }
+        __syncthreads();
+        BLK_STAMP(8);
+        // ---- wave = key tile: S^T = K Q^T (a query is a lane column), softmax pieces, O^T = V^T P^T
+        {
+            const int kt = wave;
+            float m = -INFINITY, lsum = 0.f;
+            f32x4 oacc[NDT];
+#pragma unroll
+            for (int o = 0; o < NDT; ++o) oacc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+                f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NDT; ++u) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + jl) * KSTR + 16 * u + 4 * g);
+                    const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + jl * KSTR + 16 * u + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[e], sacc, 0, 0, 0);
+                }
+                const int qtok = q0 + jl;                                  // this lane's query (column jl)
+                const int qpl = qtok >= b2 ? 2 : (qtok >= b1 ? 1 : 0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int key = k0 + 16 * kt + 4 * g + rr;
+                    const int kpl = key >= b2 ? 2 : (key >= b1 ? 1 : 0);
+                    const bool dead = key >= k1 || (!a.whole && kpl != qpl);
+                    sacc[rr] = dead ? -INFINITY : sacc[rr];
+                    m = fmaxf(m, sacc[rr]);
+                }
+                m = blk_swap_max16(m);
+                m = blk_swap_max32(m);
+                const bool live = m != -INFINITY;                          // (a key tile may hold only keys of other planes)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float pz = live ? __builtin_amdgcn_exp2f(sacc[rr] - m) : 0.f;
+                    sacc[rr] = pz;
+                    lsum += pz;
+                }
+                lsum += __shfl_xor(lsum, 16);
+                lsum += __shfl_xor(lsum, 32);
+#pragma unroll
+                for (int o = 0; o < NDT; ++o) {
+                    const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (16 * o + jl) * VSTR + 16 * kt + 4 * g);
+#pragma unroll
+                    for (int sI = 0; sI < 4; ++sI) oacc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[sI], sacc[sI], oacc[o], 0, 0, 0);
+                }
+            }
+            // park (m, l, O^T) of this key tile: O^T lane (query jl, group g) reg r = d index 16 o + 4 g + r
+            float* op = Os + ((size_t)wave * 16 + jl) * KSTR + 4 * g;
+#pragma unroll
+            for (int o = 0; o < NDT; ++o) *reinterpret_cast<f32x4*>(op + 16 * o) = oacc[o];
+            if (g == 0) { ml[(wave * 16 + jl) * 2] = m; ml[(wave * 16 + jl) * 2 + 1] = lsum; }
+        }
+        __syncthreads();
+        // ---- merge the key tiles of every query: thread -> (query row, d quad)
+        if (tid < 16 * QPR) {
+            const int qr = tid / QPR, dq = tid - qr * QPR;
+            float M = -INFINITY;
+            for (int w = 0; w < nkt; ++w) M = fmaxf(M, ml[(w * 16 + qr) * 2]);
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            float lt = 0.f;
+            for (int w = 0; w < nkt; ++w) {
+                const float mm = ml[(w * 16 + qr) * 2];
+                const float f = mm == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mm - M);
+                lt += ml[(w * 16 + qr) * 2 + 1] * f;
+                o += *reinterpret_cast<const f32x4*>(Os + ((size_t)w * 16 + qr) * KSTR + 4 * dq) * f;
+            }
+            const float inv = lt > 0.f ? 1.0f / lt : 0.f;                  // (rows past L: no live key)
+            *reinterpret_cast<f32x4*>(Att + qr * AS + 4 * dq) = o * inv;
+        }
+        __syncthreads();
+        BLK_STAMP(9);
+        // ---- proj: [16 rows][ncols] = Att [16][D] x Wp[cols][h D ..]^T; wave -> column tiles wave, wave + 8
+        {
+            f32x4 af[NDT];
+#pragma unroll
+            for (int cc = 0; cc < NDT; ++cc) af[cc] = *reinterpret_cast<const f32x4*>(Att + jl * AS + 16 * cc + 4 * g);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int ct = wave + 8 * pt;
+                if (ct < nct2) {
+                    f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int cc = 0; cc < NDT; ++cc)
+#pragma unroll
+                        for (int sI = 0; sI < 4; ++sI) pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cc][sI], wp[pt][cc][sI], pacc, 0, 0, 0);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) po[(4 * g + rr) * POS + 16 * ct + jl] = pacc[rr];
+                }
+            }
+        }
+        __syncthreads();
+        // epilogue: thread -> (row, column quad); slab h = proj partial of head h + input slabs h, h + H, ... (+ bias in slab 0)
+        float* const outp = a.out + (size_t)h * a.out_slab_stride;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int e = tid + BLK_NTH * u;
+            const int rr = e / nq4, cq = e - rr * nq4;
+            const int tok = q0 + rr;
+            if (e >= 16 * nq4 || tok >= L) continue;
+            const int n = cp * a.ncols + 4 * cq;
+            f32x4 v = *reinterpret_cast<const f32x4*>(po + rr * POS + 4 * cq);
+            v += rres[u];
+            for (int k = h + H; k < xks; k += H)
+                v += *reinterpret_cast<const f32x4*>(a.x.p + (size_t)k * a.x.slab_stride + ((size_t)b * L + tok) * a.x.C + n);
+            if (h == 0) v += *reinterpret_cast<const f32x4*>(a.bp + n);
+            *reinterpret_cast<f32x4*>(outp + ((size_t)b * L + tok) * C + n) = v;
+        }
+        __syncthreads();                                                    // (LDS is reused by the next item)
+    }
+    BLK_STAMP(10);
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+size_t deep_block_smem_bytes(const DeepBlockArgs& a) {
+    const int D = a.C / a.H;
+    return (size_t)blk_lds(a.L, D, a.CS, a.ncols).total * 4;
+}
+
+// Cluster size / slicing of one attention block.  `a` arrives with B, L, C, H, r, t, whole, gs and the input set; on success CL, CS
+// and the stage-2 / stage-3 work split are filled in.  false: this block keeps the three-launch path of deep.hip.
+bool deep_block_configure(DeepBlockArgs& a, int force_cl) {
+    if (a.B < 1 || a.H < 1 || a.L < 1 || a.L > 128 || a.C % a.H || (a.C & 15)) return false;
+    if (a.H > 8 || (a.H & (a.H - 1))) return false;                      // the heads are the output slabs: 1, 2, 4 or 8
+    const int d = a.C / a.H;
+    if (d != 16 && d != 32 && d != 64) return false;
+    if (a.gs < 1 || a.C % a.gs) return false;
+    if (!(a.x.ks == 1 || a.x.ks == 2 || a.x.ks == 4 || a.x.ks == 8)) return false;
+    const int nqt = (a.L + 15) / 16;
+    int best = 0;
+    for (int CL = 1; CL <= 16; CL *= 2) {
+        if (force_cl > 0 && CL != force_cl) continue;
+        if (a.C % CL) continue;
+        const int CS = a.C / CL;
+        if (CS < 16 || CS > 64 || (CS & (CS - 1)) || CS % a.gs || CS / a.gs > BLK_MAX_NG) continue;
+        if ((long)a.B * a.H * CL > 128) continue;                          // all workgroups resident together, on half the chip
+        int ncp = CL > nqt ? CL / nqt : 1;                               // column parts: one stage-3 item per workgroup where the cluster allows,
+        while (a.C / ncp > 256) ncp *= 2;                                 // at most 256 columns per item (two column tiles per wave)
+        if (a.C % ncp) continue;
+        const int ncols = a.C / ncp;
+        if (ncols > 256 || (ncols & 15)) continue;
+        DeepBlockArgs probe = a;
+        probe.CS = CS; probe.ncols = ncols;
+        if (deep_block_smem_bytes(probe) > 160 * 1024) continue;
+        best = CL;                                                          // the largest admissible cluster
+    }
+    if (!best) return false;
+    a.CL = best;
+    a.CS = a.C / best;
+    a.nqt = nqt;
+    a.ncp = best > nqt ? best / nqt : 1;
+    while (a.C / a.ncp > 256) a.ncp *= 2;
+    a.ncols = a.C / a.ncp;
+    a.rows_per = (a.L + best - 1) / best;
+    return true;
+}
+
+size_t deep_block_part_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.CL * a.L * 3 * a.C; }
+size_t deep_block_qkv_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.L * 3 * a.C; }
+
+hipError_t launch_deep_block(const DeepBlockArgs& a0, hipStream_t s) {
+    DeepBlockArgs a = a0;
+    const int d = a.C / a.H;
+    if (a.CL < 1 || (a.CL & (a.CL - 1)) || a.CL > 16 || a.CS * a.CL != a.C || a.CS < 16 || a.CS > 64) return hipErrorInvalidValue;
+    if ((long)a.B * a.H * a.CL > 128 || a.ncols > 256 || (a.ncols & 15) || a.ncols * a.ncp != a.C) return hipErrorInvalidValue;
+    if (!a.part || !a.qkv || !a.cnt || !a.fault || !a.x.p || !a.out) return hipErrorInvalidValue;
+    a.cl_shift = __builtin_ctz(a.CL);
+    a.qw_shift = __builtin_ctz(a.CS / 4);
+    {
+        const double gsd = (double)a.gs;
+        a.inv_n[0] = 1.0 / ((double)a.r * a.r * gsd);
+        a.inv_n[1] = a.inv_n[2] = 1.0 / ((double)a.t * a.r * gsd);
+        a.inv_n[3] = 1.0 / ((double)a.L * gsd);
+    }
+    const size_t smem = deep_block_smem_bytes(a);
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(a.B * a.H * a.CL));
+    if (d == 16) hipLaunchKernelGGL((k_deep_block<16>), grid, dim3(BLK_NTH), smem, s, a);
+    else if (d == 32) hipLaunchKernelGGL((k_deep_block<32>), grid, dim3(BLK_NTH), smem, s, a);
+    else if (d == 64) hipLaunchKernelGGL((k_deep_block<64>), grid, dim3(BLK_NTH), smem, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t deep_block_init_attrs() {
+    const void* fn[] = {reinterpret_cast<const void*>(&k_deep_block<16>), reinterpret_cast<const void*>(&k_deep_block<32>),
+                        reinterpret_cast<const void*>(&k_deep_block<64>)};
+    for (const void* f : fn) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace mtv

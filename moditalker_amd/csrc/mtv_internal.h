@@ -334,6 +334,36 @@ struct DeepAttnArgs {
     DeepFin fin;
 };
 
+// One whole attention block of a deep level in ONE launch (block.hip, k_deep_block): GroupNorm -> qkv -> attention -> proj_out +
+// residual, cut along heads -- a cluster of CL workgroups owns one (clip, head); two in-launch hand-offs inside the cluster.
+struct DeepBlockArgs {
+    DeepSrc x;               // the block's input (also its residual): [ks][clips][L][C]
+    int B, L, C, H;          // head dim d = C / H (16, 32 or 64); H = 1, 2, 4 or 8 (the heads are the output slabs)
+    int r, t;                // plane geometry of the level: xy r x r | yt t x r | xt t x r
+    int whole;               // 1: AttentionBlock1D -- statistics and attention over all L tokens; 0: per plane
+    float scale;             // d^-1/4, applied to q and to k (unet.py:322-323)
+    const float* gamma;      // GroupNorm affine [C]
+    const float* beta;
+    int gs;                  // channels per GroupNorm group (C / 32)
+    const float* Wq;         // qkv weight as the checkpoint stores it: [3C][C], row = output channel head * 3d + {q: 0.., k: d.., v: 2d..}
+    const float* bq;         // [3C]
+    const float* Wp;         // proj_out weight as stored: [C][C], row = output channel
+    const float* bp;         // [C]
+    float* out;              // slab 0 of [H][clips][L][C]: slab h = head h's share of the projection (+ input slabs h, h + H, ...; bias in slab 0)
+    unsigned out_slab_stride;
+    int CL, CS;              // workgroups per cluster = K slices of the qkv GEMM; channels per slice = C / CL
+    float* part;             // scratch [B H][CL][L][3d]: partial qkv of the K slices
+    float* qkv;              // scratch [B H][L][3d]: the head's q | k | v rows (bias added)
+    unsigned long long* cnt; // [B H][2] monotonic arrival counters of the two hand-offs (never reset)
+    int* fault;              // set when a hand-off wait timed out
+    int rows_per;            // stage 2: rows a workgroup reduces = ceil(L / CL)
+    int nqt, ncp, ncols;     // stage 3: query tiles, column parts, columns per part (C / ncp <= 256)
+    // ---- derived by launch_deep_block
+    int cl_shift, qw_shift;  // log2(CL), log2(CS / 4)
+    double inv_n[4];         // 1 / (tokens x gs) of plane 0, 1, 2 and of all planes together
+    unsigned long long* dbg; // -DMTV_DEEP_STAMP builds: phase timestamps, else unused
+};
+
 struct LinearArgs {
     const float* x;          // [B][K]
     const float* W;          // [N][K]
@@ -419,6 +449,13 @@ hipError_t launch_deep_finalize(const DeepFinArgs& a, hipStream_t s);
 bool deep_attn_configure(DeepAttnArgs& a);                // fills HPW / NC / group counts; false: this block keeps k_attention + a proj conv
 hipError_t launch_deep_attn(const DeepAttnArgs& a, hipStream_t s);
 hipError_t deep_init_attrs();
+// whole attention block of a deep level in one launch (block.hip)
+bool deep_block_configure(DeepBlockArgs& a, int force_cl = 0);   // picks the cluster size (force_cl > 0: that one or nothing); false: keep the three-launch path
+size_t deep_block_smem_bytes(const DeepBlockArgs& a);
+size_t deep_block_part_floats(const DeepBlockArgs& a);    // scratch sizes of a configured block
+size_t deep_block_qkv_floats(const DeepBlockArgs& a);
+hipError_t launch_deep_block(const DeepBlockArgs& a, hipStream_t s);
+hipError_t deep_block_init_attrs();
 hipError_t launch_linear(const LinearArgs& a, hipStream_t s);
 hipError_t launch_time_sinusoid(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
 hipError_t launch_pack_input(const float* x, const float* cond, const float* image_cond, int ic_len,

@@ -749,6 +749,58 @@ struct Builder {
         da.Wp = Wp; da.ldw = ldp; da.bias = bp;
         const bool fuse_env = !deep_opt(MTV_DEEP_OPT_NO_FUSED_ATTN, "MTV_DEEP_NO_ATTN", false);
         const bool deep_qkv_env = deep_opt(MTV_DEEP_OPT_SLICED_QKV, "MTV_DEEP_QKV", false);
+        // ---- the whole block in ONE launch (block.hip, k_deep_block): a cluster of workgroups per (clip, head) reads the input's slabs,
+        // computes its GroupNorm statistics, the head's q | k | v (K-sliced inside the cluster, two in-launch hand-offs), the attention and
+        // the head's share of proj_out -> output slab `head`.  No finalize pass, no statistics site, no plain qkv tensor.
+        // (the dataflow variants of round 4 describe the three-launch form: any of them selects it)
+        const bool block_env = !deep_opt(MTV_DEEP_OPT_NO_BLOCK, "MTV_DEEP_NO_BLOCK", false) && fuse_env && !deep_qkv_env &&
+                               !deep_opt(MTV_DEEP_OPT_UNSLICED_QKV, "MTV_DEEP_QKV1", false) && !deep_opt(MTV_DEEP_OPT_INLAUNCH, "MTV_DEEP_INLAUNCH", false);
+        if (deep_on(lvl) && block_env) {
+            DeepBlockArgs ba{};
+            ba.x = dsrc(x0);
+            ba.B = B; ba.L = L.L; ba.C = C; ba.H = H; ba.r = L.r; ba.t = L.t; ba.whole = whole ? 1 : 0;
+            ba.scale = 1.0f / std::sqrt(std::sqrt((float)d));
+            ba.gamma = gw; ba.beta = gb; ba.gs = C / 32;
+            ba.Wq = Wq_nk; ba.bq = bq; ba.Wp = Wp_nk; ba.bp = bp;
+            static const int force_cl = []() { const char* e = getenv("MTV_BLOCK_CL"); return e ? atoi(e) : 0; }();
+            if (deep_block_configure(ba, force_cl) || (force_cl && deep_block_configure(ba, 0))) {
+                Tens out;
+                out.lvl = lvl; out.C = C; out.ks = H;
+                out.slab = (unsigned)((size_t)deep_clips() * L.L * C);
+                out.p = c->buf("act.deep." + nm + ".out", (size_t)8 * out.slab);
+                // scratch shared by every block of the context that needs the same size (the launches of a plan are serial)
+                const size_t pf = deep_block_part_floats(ba), qf = deep_block_qkv_floats(ba);
+                ba.part = c->buf("deep.block.part." + std::to_string(pf), pf);
+                ba.qkv = c->buf("deep.block.qkv." + std::to_string(qf), qf);
+                // arrival counters: 64-bit, monotonic (never reset), one pair per (clip, head) of THIS op: plans of different batch sizes
+                // cut clusters differently
+                ba.cnt = reinterpret_cast<unsigned long long*>(c->buf("deep.block.cnt." + nm + ".B" + std::to_string(B) + ".CL" + std::to_string(ba.CL), (size_t)B * H * 2 * 2));
+                ba.fault = c->fault_d;
+                ba.out = out.p;
+                ba.out_slab_stride = out.slab;
+                if (!out.p || !ba.part || !ba.qkv || !ba.cnt || !ba.fault) { err = "deep block allocation failed at " + nm; return Tens{}; }
+                c->taps[nm + ".out"] = {lvl, C};
+                c->bufs["tap." + nm + ".out"] = out.p;
+                c->tap_slabs[nm + ".out"] = {out.ks, out.slab};
+                double aflops = 0.0;
+                {
+                    const int segs[3] = {L.b1, L.b2 - L.b1, L.L - L.b2};
+                    if (whole) aflops = 4.0 * B * H * (double)L.L * L.L * d;
+                    else for (int sg : segs) aflops += 4.0 * B * H * (double)sg * sg * d;
+                }
+                if (c->accounting) {
+                    c->work.flops_attn_core += aflops / B;
+                    c->work.flops_1x1 += 2.0 * (double)L.L * C * 3.0 * C + 2.0 * (double)L.L * C * C;
+                    c->work.bytes_weights_other += 4.0 * (4.0 * (double)C * C + 4.0 * C);
+                }
+                char tag[96];
+                snprintf(tag, sizeof tag, "[L%d d%d %s blk cl%d,cs%d]", L.L, d, whole ? "1d" : "2d", ba.CL, ba.CS);
+                auto bop = std::make_shared<DeepBlockArgs>(ba);
+                push("attn:" + nm + tag, [bop](hipStream_t s) { return launch_deep_block(*bop, s); },
+                     aflops + 2.0 * B * (double)L.L * C * 4.0 * C, 4.0 * B * L.L * (2.0 * C) + 4.0 * (4.0 * (double)C * C + 4.0 * C));
+                return out;
+            }
+        }
         const bool fused = deep_on(lvl) && fuse_env && deep_attn_configure(da);
         auto emit_fused = [&](const float* qkv_plain, const Tens& xres) -> Tens {
             Tens out;
@@ -1444,6 +1496,12 @@ int ctx_init_common(mtv_ctx* c) {
     HIPCHK(conv_init_attrs());     // dynamic LDS above 64 KB must be opted into once per kernel (never under capture)
     HIPCHK(attn_init_attrs());
     HIPCHK(deep_init_attrs());
+    HIPCHK(deep_block_init_attrs());
+    if (!c->fault_h) {     // device-side fault word (k_deep_block: a hand-off wait that timed out), host-mapped: checked without a copy
+        HIPCHK(hipHostMalloc((void**)&c->fault_h, 64, hipHostMallocMapped));
+        *c->fault_h = 0;
+        HIPCHK(hipHostGetDevicePointer((void**)&c->fault_d, c->fault_h, 0));
+    }
     return MTV_OK;
 }
 
@@ -1629,6 +1687,9 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
 
 int check_ready(mtv_ctx* c, int batch) {
     if (!c) return fail(MTV_ERR_INVALID, "null context");
+    if (c->fault_h && *(volatile int*)c->fault_h)
+        return fail(MTV_ERR_STATE, "an in-launch hand-off of k_deep_block timed out in an earlier call (results since then are invalid): destroy this context; "
+                                   "MTV_DEEP_NO_BLOCK=1 selects the three-launch attention block");
     if (batch < 1 || batch > c->cfg.max_batch) return fail(MTV_ERR_STATE, "batch outside [1, max_batch]");
     const int miss = mtv_weights_missing(c);
     if (miss) {
@@ -2038,7 +2099,7 @@ int mtv_debug_deep(int mode) {
 }
 
 int mtv_debug_deep_options(int mask) {
-    if (mask < -1 || mask > 15) return fail(MTV_ERR_INVALID, "mask must be -1 (environment / defaults) or a combination of MTV_DEEP_OPT_*");
+    if (mask < -1 || mask > 31) return fail(MTV_ERR_INVALID, "mask must be -1 (environment / defaults) or a combination of MTV_DEEP_OPT_*");
     g_deep_opts = mask;
     return MTV_OK;
 }

@@ -176,6 +176,8 @@ struct mtv_ctx {
     bool eager = false;
     mtv_work work{};
     bool accounting = false;
+    int* fault_h = nullptr;                      // host-mapped fault word of the in-launch hand-offs (block.hip) and its device address
+    int* fault_d = nullptr;
     float* staging = nullptr;
     size_t staging_floats = 0;
     // split-bf16 copies of conv / GEMM weight matrices (k_conv_x3): W [K][ld] f32 -> three bf16 planes, rebuilt after weight loads
@@ -282,6 +284,7 @@ struct mtv_ctx {
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (void* p : allocs) (void)hipFree(p);
         if (staging) (void)hipFree(staging);
+        if (fault_h) (void)hipHostFree(fault_h);
         free_step_tables();
         for (int i = 0; i < 2; ++i) {
             if (h_pin[i]) (void)hipHostFree(h_pin[i]);

@@ -514,22 +514,32 @@ def _base_eps_and_sample(lib, names_out=None):
 
 
 def test_deep_levels_are_on_by_default_and_off_keeps_the_k_conv_path_green():
-    """Default plan of the base UNet at one clip: the convs of levels 2 / 3 (<= 128 tokens) run on k_deep_conv and their attention
-    blocks on the fused k_deep_attn; mtv_debug_deep(0) puts every conv back on k_conv.  Both against the reference golden."""
+    """Default plan of the base UNet at one clip: the convs of levels 2 / 3 (<= 128 tokens) run on k_deep_conv and each of their 18
+    attention blocks is ONE launch of k_deep_block (csrc/block.hip: no finalize pass, no qkv launch); MTV_DEEP_OPT_NO_BLOCK selects
+    round 4's three launches per block; mtv_debug_deep(0) puts every conv back on k_conv.  All against the reference golden."""
     from moditalker_amd import _lib
     lib = _lib.load()
     names = []
     e1, s1 = _base_eps_and_sample(lib, names)
     assert e1 <= FWD_TOL and s1 <= SAMPLE_TOL, (e1, s1)
     deep = [n for n in names if n.startswith("conv") and " d" in n.split("[")[-1]]
-    fused = [n for n in names if n.startswith("attn") and "+proj" in n]
-    assert len(deep) >= 28 and len(fused) == 18, (len(deep), len(fused))
+    blocks = [n for n in names if n.startswith("attn") and " blk " in n]
+    fins = [n for n in names if n.startswith("fin")]
+    assert len(deep) >= 28 and len(blocks) == 18 and len(fins) <= 4 and len(names) <= 150, (len(deep), len(blocks), len(fins), len(names))
+    _lib.check(lib.mtv_debug_deep_options(16), "mtv_debug_deep_options")
+    try:
+        names = []
+        e2, s2 = _base_eps_and_sample(lib, names)
+        assert e2 <= FWD_TOL and s2 <= SAMPLE_TOL, (e2, s2)
+        assert len([n for n in names if n.startswith("attn") and "+proj" in n]) == 18 and not [n for n in names if " blk " in n]
+    finally:
+        lib.mtv_debug_deep_options(-1)
     _lib.check(lib.mtv_debug_deep(0), "mtv_debug_deep")
     try:
         names = []
         e0, s0 = _base_eps_and_sample(lib, names)
         assert e0 <= FWD_TOL and s0 <= SAMPLE_TOL, (e0, s0)
-        assert not [n for n in names if "+proj" in n or n.startswith("fin")], "deep kernels in a plan built with them switched off"
+        assert not [n for n in names if "+proj" in n or " blk " in n or n.startswith("fin")], "deep kernels in a plan built with them switched off"
     finally:
         lib.mtv_debug_deep(-1)
 
@@ -559,12 +569,14 @@ def test_deep_level_dataflow_variants_vs_reference_golden(mask):
 def test_deep_kernels_against_cpu_conv_and_attention():
     """tools/ubench/deep_bench (built by __graft_entry__.build): k_deep_conv on 19 shapes (3x3 / 1x1, concatenated sources, fused skip
     conv, residuals in slabs, upsampled sources, both row groupings, ragged planes, two clips, the base model's full-size shapes)
-    and k_deep_attn on 9 (1-D / per-plane, head dims 16 / 32 / 64, ragged) against plain CPU restatements in double."""
+    and k_deep_attn on 9 (1-D / per-plane, head dims 16 / 32 / 64, ragged) against plain CPU restatements in double; k_deep_block
+    (csrc/block.hip, the whole attention block in one launch) on 13 shapes -- 1 / 2 clips, 1-8 input slabs, head dims 16 / 32 / 64,
+    GroupNorm groups of 1 - 16 channels, ragged planes -- against a double-precision GroupNorm -> qkv -> attention -> proj_out."""
     import subprocess
     exe = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "ubench", "deep_bench")
     if not os.path.exists(exe):
         pytest.skip("tools/ubench/deep_bench not built (python -c 'import __graft_entry__ as g; g.build()')")
-    for mode, ok in (("check", "CHECK OK"), ("attn", "ATTN CHECK OK")):
+    for mode, ok in (("check", "CHECK OK"), ("attn", "ATTN CHECK OK"), ("block", "BLOCK CHECK OK")):
         out = subprocess.run([exe, mode], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and ok in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 

@@ -41,7 +41,7 @@ for us, k in tab:
         f += " M" + re.search(r"\[(\d+)x", k).group(1)
     if f == "attn":
         mm = re.search(r"\[L(\d+) d(\d+) (\w+)", k)
-        f += f" L{mm.group(1)} {mm.group(3)}"
+        f += f" L{mm.group(1)} {mm.group(3)}" + (" blk" if " blk " in k else "")
     fam[f][0] += 1
     fam[f][1] += us
 out = [f"# median GPU duration per launch of one DDIM step (rocprofv3 kernel trace, {len(idx) - 23} steady-state steps), plan order"]

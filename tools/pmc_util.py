@@ -16,7 +16,7 @@ import statistics
 
 def fam_of(name):
     n = name.split("(")[0].replace("void ", "").replace("mtv::", "")
-    for k in ("k_conv_lds", "k_conv", "k_lin", "k_deep_conv", "k_deep_attn", "k_deep_finalize", "k_attention_b3", "k_attention", "k_pool_down"):
+    for k in ("k_conv_lds", "k_conv", "k_lin", "k_deep_conv", "k_deep_attn", "k_deep_block", "k_deep_finalize", "k_attention_b3", "k_attention", "k_pool_down"):
         if n.startswith(k):
             # (k_deep_conv: the K-sliced convs of the <= 128-token levels, csrc/deep.hip -- part of the conv family)
             return {"k_conv_lds": "k_conv", "k_lin": "k_conv", "k_deep_conv": "k_conv", "k_attention_b3": "k_attention"}.get(k, k)

@@ -7,6 +7,7 @@
 //   deep_bench chain [nops] [r t]   timing (default 40 ops = 377 MB of weights: larger than the 256 MB Infinity Cache; r t = 4 2)
 #include "../../moditalker_amd/csrc/conv.hip"
 #include "../../moditalker_amd/csrc/deep.hip"
+#include "../../moditalker_amd/csrc/block.hip"
 #include <cmath>
 #include <functional>
 #include <cstring>
@@ -456,6 +457,167 @@ static int do_attn(bool timing) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------- k_deep_block
+// the whole attention block in one launch (block.hip) against a double-precision CPU restatement of
+// GroupNorm -> qkv -> QKVAttentionLegacy -> proj_out + residual; the reduced qkv scratch is checked too (localises a failure)
+static int run_block(int r, int t, int C, int H, int whole, int x_ks, int B, int force_cl, bool timing) {
+    const int b1 = r * r, b2 = b1 + t * r, L = b2 + t * r, d = C / H, gs = C / 32 > 0 ? C / 32 : 1;
+    std::vector<float> Wq((size_t)3 * C * C), bq(3 * C), Wp((size_t)C * C), bp(C), ga(C), be(C), xr;
+    const float wsc = 1.0f / sqrtf((float)C);
+    for (auto& v : Wq) v = frand() * wsc;
+    for (auto& v : Wp) v = frand() * wsc;
+    for (auto& v : bq) v = frand() * 0.1f;
+    for (auto& v : bp) v = frand() * 0.1f;
+    for (auto& v : ga) v = 1.0f + 0.2f * frand();
+    for (auto& v : be) v = 0.2f * frand();
+    DeepBlockArgs a{};
+    a.x = make_src(B, L, C, x_ks, xr);
+    a.B = B; a.L = L; a.C = C; a.H = H; a.r = r; a.t = t; a.whole = whole;
+    a.scale = 1.0f / sqrtf(sqrtf((float)d));
+    a.gamma = dup(ga); a.beta = dup(be); a.gs = gs;
+    a.Wq = dup(Wq); a.bq = dup(bq); a.Wp = dup(Wp); a.bp = dup(bp);
+    if (!deep_block_configure(a, force_cl)) { printf("block L%d C%d d%d cl%d: not configurable\n", L, C, d, force_cl); return force_cl ? 0 : 1; }
+    const size_t slab = (size_t)B * L * C;
+    float* out = dnew<float>((size_t)8 * slab);
+    a.out = out; a.out_slab_stride = (unsigned)slab;
+    a.part = dnew<float>(deep_block_part_floats(a));
+    a.qkv = dnew<float>(deep_block_qkv_floats(a));
+    a.cnt = dnew<unsigned long long>((size_t)B * H * 2);
+    a.fault = dnew<int>(16);
+#ifdef MTV_DEEP_STAMP
+    a.dbg = dnew<unsigned long long>(64);
+#endif
+    CK(hipMemset(out, 0xFF, (size_t)8 * slab * 4));
+    int fault = 0;
+    std::vector<float> got((size_t)H * slab), gq(deep_block_qkv_floats(a));
+    // twice: the second launch runs on counters the first one left behind (monotonic, never reset)
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(launch_deep_block(a, 0));
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipMemcpy(&fault, a.fault, 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gq.data(), a.qkv, gq.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0, sc2 = 0, worst_q = 0;
+    bool nan = false;
+    for (int b = 0; b < B; ++b) {
+        const float* x = xr.data() + (size_t)b * L * C;
+        // GroupNorm (biased variance, eps 1e-5) per plane or over all planes
+        std::vector<double> xn((size_t)L * C), qkv((size_t)L * 3 * C), att((size_t)L * C);
+        for (int g = 0; g < C / gs; ++g)
+            for (int p = 0; p < (whole ? 1 : 3); ++p) {
+                const int t0 = whole ? 0 : (p == 0 ? 0 : (p == 1 ? b1 : b2)), t1 = whole ? L : (p == 0 ? b1 : (p == 1 ? b2 : L));
+                double sm = 0, sq = 0;
+                for (int tk = t0; tk < t1; ++tk)
+                    for (int c = g * gs; c < (g + 1) * gs; ++c) { sm += x[(size_t)tk * C + c]; sq += (double)x[(size_t)tk * C + c] * x[(size_t)tk * C + c]; }
+                const double n = (double)(t1 - t0) * gs, mean = sm / n, var = sq / n - mean * mean, rstd = 1.0 / sqrt(var + 1e-5);
+                for (int tk = t0; tk < t1; ++tk)
+                    for (int c = g * gs; c < (g + 1) * gs; ++c) xn[(size_t)tk * C + c] = (x[(size_t)tk * C + c] - mean) * rstd * ga[c] + be[c];
+            }
+        for (int tk = 0; tk < L; ++tk)
+            for (int n = 0; n < 3 * C; ++n) {
+                double o = bq[n];
+                for (int c = 0; c < C; ++c) o += xn[(size_t)tk * C + c] * Wq[(size_t)n * C + c];
+                qkv[(size_t)tk * 3 * C + n] = o;
+                const int hh = n / (3 * d), col = n - hh * 3 * d;
+                const float gv = gq[(((size_t)b * H + hh) * L + tk) * 3 * d + col];
+                if (gv != gv) nan = true;
+                worst_q = std::max(worst_q, fabs((double)gv - o));
+            }
+        for (int h = 0; h < H; ++h)
+            for (int q = 0; q < L; ++q) {
+                const int qp = q >= b2 ? 2 : (q >= b1 ? 1 : 0);
+                std::vector<double> sc(L, -1e300);
+                double mx = -1e300;
+                for (int k = 0; k < L; ++k) {
+                    const int kp = k >= b2 ? 2 : (k >= b1 ? 1 : 0);
+                    if (!whole && kp != qp) continue;
+                    double sx = 0;
+                    for (int e = 0; e < d; ++e) sx += qkv[(size_t)q * 3 * C + h * 3 * d + e] * qkv[(size_t)k * 3 * C + h * 3 * d + d + e];
+                    sc[k] = sx / sqrt((double)d);
+                    mx = std::max(mx, sc[k]);
+                }
+                double den = 0;
+                for (int k = 0; k < L; ++k) if (sc[k] > -1e299) { sc[k] = exp(sc[k] - mx); den += sc[k]; } else sc[k] = 0;
+                for (int e = 0; e < d; ++e) {
+                    double o = 0;
+                    for (int k = 0; k < L; ++k) o += sc[k] * qkv[(size_t)k * 3 * C + h * 3 * d + 2 * d + e];
+                    att[(size_t)q * C + h * d + e] = o / den;
+                }
+            }
+        for (int q = 0; q < L; ++q)
+            for (int n = 0; n < C; ++n) {
+                double o = bp[n] + x[(size_t)q * C + n];
+                for (int k = 0; k < C; ++k) o += att[(size_t)q * C + k] * Wp[(size_t)n * C + k];
+                double s2 = 0;
+                for (int k = 0; k < H; ++k) { const float v = got[(size_t)k * slab + ((size_t)b * L + q) * C + n]; if (v != v) nan = true; s2 += v; }
+                worst = std::max(worst, fabs(s2 - o));
+                sc2 = std::max(sc2, fabs(o));
+            }
+    }
+    const bool ok = !nan && !fault && worst <= 1e-4 * std::max(1.0, sc2) && worst_q <= 1e-4 * 8;
+    printf("block L%-3d C%-3d d%-2d H%d %s x_ks%d B%d  cl%d cs%d -> %d WGs, %zu B LDS  qkv max|err| %.3e  out max|err| %.3e (|ref| <= %.2f)%s%s  %s\n", L, C, d, H,
+           whole ? "1d" : "2d", x_ks, B, a.CL, a.CS, B * H * a.CL, deep_block_smem_bytes(a), worst_q, worst, sc2, nan ? " NaN" : "", fault ? " FAULT(hand-off timeout)" : "",
+           ok ? "PASS" : "FAIL");
+    if (timing && ok) {
+        hipStream_t s; CK(hipStreamCreate(&s));
+        hipGraph_t gr; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 20; ++i) CK(launch_deep_block(a, s));
+        CK(hipStreamEndCapture(s, &gr));
+        CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < 20; ++i) CK(hipGraphLaunch(ge, s));
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpy(&fault, a.fault, 4, hipMemcpyDeviceToHost));
+        printf("    %.2f us per launch (graph of 20 back-to-back launches, boundary included)%s\n", ms * 1e3 / 400, fault ? "  FAULT" : "");
+        // bit-equal repeats: the hand-offs must never deliver a stale partial
+        std::vector<float> again(got.size());
+        CK(hipMemcpy(again.data(), out, again.size() * 4, hipMemcpyDeviceToHost));
+        size_t diff = 0;
+        for (size_t e = 0; e < got.size(); ++e) diff += memcmp(&again[e], &got[e], 4) != 0;
+        printf("    %zu of %zu output words differ from the first run after 460 more launches%s\n", diff, got.size(), diff ? "  NOT BIT-EQUAL" : "");
+        if (diff || fault) return 1;
+#ifdef MTV_DEEP_STAMP
+        unsigned long long hst[32];
+        CK(hipMemcpy(hst, a.dbg, sizeof hst, hipMemcpyDeviceToHost));
+        for (int blk = 0; blk < 2; ++blk) {
+            printf("    stamps wg %s (100 MHz ticks since entry):", blk ? "mid" : "0");
+            for (int k = 1; k < 11; ++k) if (hst[blk * 16 + k]) printf(" [%d] %lld", k, (long long)(hst[blk * 16 + k] - hst[blk * 16]));
+            printf("\n");
+        }
+#endif
+    }
+    return ok ? 0 : 1;
+}
+static int do_block(bool timing) {
+    int bad = 0;
+    bad += run_block(4, 2, 512, 8, 1, 8, 1, 0, timing);       // the base model's 32-token blocks (in9 .. out1): input = 8 slabs
+    bad += run_block(4, 2, 512, 8, 0, 8, 1, 0, timing);       // mid.1 (per plane: 16 | 8 | 8 tokens)
+    bad += run_block(8, 4, 512, 8, 1, 4, 1, 0, timing);       // 128-token blocks (in7 / in8 / out2 .. out4), AttentionBlock1D
+    bad += run_block(8, 4, 512, 8, 0, 4, 1, 0, timing);       // ... per plane (64 | 32 | 32)
+    bad += run_block(8, 4, 256, 8, 1, 8, 1, 0, timing);       // in6.a1: d = 32
+    if (timing) {                                             // other cluster sizes on the two headline shapes
+        bad += run_block(4, 2, 512, 8, 1, 8, 1, 8, true);
+        bad += run_block(8, 4, 512, 8, 1, 4, 1, 8, true);
+    }
+    bad += run_block(8, 4, 512, 8, 1, 4, 2, 0, false);        // two clips
+    bad += run_block(8, 4, 128, 8, 0, 1, 2, 0, false);        // the test-size model: d = 16, groups of 4 channels
+    bad += run_block(8, 4, 128, 8, 1, 2, 1, 0, false);
+    bad += run_block(6, 3, 256, 8, 0, 1, 1, 0, false);        // ragged planes 36 | 18 | 18 (72 tokens: 5 query tiles)
+    bad += run_block(6, 3, 256, 8, 1, 2, 2, 0, false);
+    bad += run_block(3, 1, 128, 2, 0, 1, 1, 0, false);        // 15 tokens, d = 64, two heads
+    bad += run_block(8, 4, 64, 2, 0, 2, 1, 0, false);         // groups of 2 channels (narrow test model at a small geometry)
+    bad += run_block(4, 2, 32, 2, 1, 1, 2, 0, false);         // groups of 1 channel, d = 16
+    printf("%s (%d failing)\n", bad ? "BLOCK CHECK FAILED" : "BLOCK CHECK OK", bad);
+    return bad;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------- k_conv_win
 // chain of dependent 3x3 convs of a LARGE level ([L x C] -> [L x C], GroupNorm + SiLU in the prologue, statistics by the epilogue),
 // distinct weights per op: k_conv tiles against the k_conv_win tiles, us per op inside one hipGraph; stamps of the win kernel
@@ -653,6 +815,7 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "attn")) { CK(deep_init_attrs()); return do_attn(argc >= 3); }
+    if (argc >= 2 && !strcmp(argv[1], "block")) { CK(deep_block_init_attrs()); return do_block(argc >= 3); }
     printf("usage: deep_bench check | chain [nops] [r t] | attn [time]\n");
     return 1;
 }
