@@ -186,13 +186,16 @@ int mtv_debug_deep(int mode);
  *                               one-launch k_deep_block (csrc/block.hip: GroupNorm -> qkv -> attention -> proj_out in one kernel, a
  *                               cluster of workgroups per head, two in-launch hand-offs); the four bits above imply it where they
  *                               change the block's dataflow (they describe the three-launch form);
- * -1 = back to the defaults / the MTV_DEEP_INLAUNCH, MTV_DEEP_QKV, MTV_DEEP_QKV1, MTV_DEEP_NO_ATTN, MTV_DEEP_NO_BLOCK environment
- * variables. */
+ *   MTV_DEEP_OPT_BLOCK_ALL      k_deep_block for EVERY attention block of the deep levels it can run, not only where it measures faster
+ *                               (by default: 32-token blocks and [128 x 256]; at [128 x 512] the three-launch form is faster);
+ * -1 = back to the defaults / the MTV_DEEP_INLAUNCH, MTV_DEEP_QKV, MTV_DEEP_QKV1, MTV_DEEP_NO_ATTN, MTV_DEEP_NO_BLOCK, MTV_DEEP_BLOCK_ALL
+ * environment variables. */
 #define MTV_DEEP_OPT_INLAUNCH 1
 #define MTV_DEEP_OPT_SLICED_QKV 2
 #define MTV_DEEP_OPT_UNSLICED_QKV 4
 #define MTV_DEEP_OPT_NO_FUSED_ATTN 8
 #define MTV_DEEP_OPT_NO_BLOCK 16
+#define MTV_DEEP_OPT_BLOCK_ALL 32
 int mtv_debug_deep_options(int mask);
 
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */

@@ -41,7 +41,10 @@ namespace {
 
 constexpr int BLK_NTH = 512;
 constexpr int BLK_MAX_NG = 32;        // GroupNorm groups per channel slice
-constexpr unsigned long long BLK_WAIT_TICKS = 2000000ull;     // s_memtime ticks (100 MHz): 20 ms
+constexpr unsigned long long BLK_WAIT_TICKS = 60000000ull;    // s_memtime ticks (shader clock, ~2.1 GHz here): ~30 ms
+constexpr int BLK_MAX_RETRY = 1 << 18;                        // granule polls per thread (x s_sleep 1: a few ms)
+constexpr int BLK_SC = 17;                                    // buffer cache policy sc0 | sc1: write-through stores, L1 / L2-bypassing loads
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 typedef __attribute__((address_space(1))) unsigned long long blk_gu64;
 
@@ -57,6 +60,19 @@ __device__ __forceinline__ f32x4 blk_fetch_quad(const float* src) {             
     const unsigned long long t0 = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t1 = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return f32x4{__uint_as_float((unsigned)t0), __uint_as_float((unsigned)(t0 >> 32)), __uint_as_float((unsigned)t1), __uint_as_float((unsigned)(t1 >> 32))};
+}
+
+// ---- data-tagged granules (MI355X_MICROARCH.md, hand-off price list: 8-byte {data, tag}, no drain, no flag): a float travels with
+// the launch's epoch; the reader re-reads a granule until its tag is this launch's.  Two granules per 16-byte store / load.
+__device__ __forceinline__ void blk_put_granules(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, const f32x4& v, unsigned tag) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag}, rs, byte_off, 0, BLK_SC);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag}, rs, byte_off + 16, 0, BLK_SC);
+}
+__device__ __forceinline__ bool blk_get_granules(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag, f32x4* out) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, BLK_SC);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 16, 0, BLK_SC);
+    *out = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(b[0]), __uint_as_float(b[2])};
+    return a[1] == tag && a[3] == tag && b[1] == tag && b[3] == tag;
 }
 
 // Cluster-wide hand-off: every workgroup of the cluster has parked its payload (all threads call this).  The counter only ever
@@ -104,6 +120,7 @@ struct BlkLds {
     int xs, wt, stat, img;  // stage 1: input slice [LP][XS] | weights [3D][WS] | statistics (doubles) | result image [LP][3D + 4] (aliases xs / wt)
     int ks, vt, qs, att, os, ml, po;   // stage 3: K rows [kcap][D + 4] | V^T [D][kcap + 4] | Q [16][D + 4] | attention rows [16][D + 8] |
                                        // key-tile partials [8][16][D + 4] | (m, l) [8][16][2] | proj image [16][ncols + 4]
+    int epoch;
     int total;
 };
 __host__ __device__ inline BlkLds blk_lds(int L, int D, int CS, int ncols) {
@@ -130,7 +147,9 @@ __host__ __device__ inline BlkLds blk_lds(int L, int D, int CS, int ncols) {
     p.ml = p.os + 8 * 16 * (D + 4);
     p.po = p.ml + 8 * 16 * 2;
     const int st3 = p.po + 16 * (ncols + 4);
-    p.total = st1 > st3 ? st1 : st3;
+    p.total = ((st1 > st3 ? st1 : st3) + 3) & ~3;
+    p.epoch = p.total;                                  // the launch's epoch (tag of the granules), written by thread 0
+    p.total += 4;
     return p;
 }
 
@@ -161,6 +180,12 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     const int qw_shift = a.qw_shift, QW = 1 << qw_shift;                 // quads per row of the slice
     const int qd = tid & (QW - 1), rl = tid >> qw_shift, RP = BLK_NTH >> qw_shift;
     unsigned long long* const cnt = a.cnt + (size_t)bh * 2;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, (int)a.part_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(a.qkv, 0, (int)a.qkv_bytes, 0x00020000);
+    // the launch's epoch: every workgroup of a cluster takes one ticket of counter 1 at entry (monotonic, exactly CL per launch):
+    // ticket n belongs to launch n / CL.  Requested now, used after stage 1 -- its round trip hides under the loads.
+    unsigned long long early = 0;
+    if (tid == 0) early = __hip_atomic_fetch_add(cnt + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // =========================================================================================================== stage 1
     // request order: input slice (first pass; L2 / Infinity-Cache warm) -> qkv weight slice -> proj fragments (HBM-cold, needed
@@ -168,10 +193,15 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     const int xks = a.x.ks;
     const float* const xcol = a.x.p + (size_t)b * L * a.x.C + cs0 + 4 * qd;
     f32x4 xv[8];
-    {
+    // (UNCONDITIONAL loads into their final registers inside a wave-uniform branch: a per-lane conditional load ends in a register copy
+    //  at the join, and a copy of a loaded value waits for every older load -- deep.hip found that three times)
+    if (blk_usgpr(rl) < L) {                               // this wave's first row (rows ascend with the lane): any row to stage?
         const int row = rl < L ? rl : 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const f32x4*>(xcol + (size_t)row * a.x.C + (size_t)(k < xks ? k : 0) * a.x.slab_stride);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     constexpr int WU = (NQ * 16 + BLK_NTH - 1) / BLK_NTH;                // weight quads per thread at CS = 64
     f32x4 wreg[WU];
@@ -181,7 +211,9 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
         for (int u = 0; u < WU; ++u) {
             const int e = tid + BLK_NTH * u;
             const int n = e >> qw_shift, wq = e & (QW - 1);
-            wreg[u] = *reinterpret_cast<const f32x4*>(wb + (size_t)(n < NQ ? n : 0) * C + 4 * wq);
+            // (whole-workgroup uniform bound: a request costs issue time on the CU's memory path whether its data is wanted or not)
+            if (BLK_NTH * u < (NQ << qw_shift)) wreg[u] = *reinterpret_cast<const f32x4*>(wb + (size_t)(n < NQ ? n : 0) * C + 4 * wq);
+            else wreg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + cs0 + 4 * qd);
@@ -194,10 +226,15 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     auto load_wp = [&](int cp) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const int ct = wave + 8 * pt;
+            const int ct = wave + 8 * pt;                                  // (wave-uniform: no request for a tile this wave does not have)
             const int n = cp * a.ncols + 16 * (ct < nct2 ? ct : 0) + jl;
+            if (ct < nct2) {
 #pragma unroll
-            for (int cc = 0; cc < NDT; ++cc) wp[pt][cc] = *reinterpret_cast<const f32x4*>(a.Wp + (size_t)n * C + h * D + 16 * cc + 4 * g);
+                for (int cc = 0; cc < NDT; ++cc) wp[pt][cc] = *reinterpret_cast<const f32x4*>(a.Wp + (size_t)n * C + h * D + 16 * cc + 4 * g);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < NDT; ++cc) wp[pt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     if (j < nitems) load_wp(j / a.nqt);
@@ -265,8 +302,10 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
         const int n = e >> qw_shift, wq = e & (QW - 1);
         if (n < NQ) *reinterpret_cast<f32x4*>(wt + n * WS + 4 * wq) = wreg[u];
     }
+    if (tid == 0) *reinterpret_cast<unsigned*>(smem + lp.epoch) = (unsigned)(early >> a.cl_shift) + 1u;     // (the ticket returned long ago)
     BLK_STAMP(2);
     __syncthreads();
+    const unsigned epoch = *reinterpret_cast<const unsigned*>(smem + lp.epoch);
     // normalise in place: y = (x - mean) rstd gamma + beta, statistics per plane or over all planes (whole)
     {
         int cur_p = -1;
@@ -326,52 +365,61 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
                 }
             }
         }
-        __syncthreads();                                                  // slice and weights are dead: the image takes their place
-        float* const img = smem + lp.img;
-        constexpr int IS = NQ + 4;
+        // the partial tiles leave as data-tagged granules straight from the accumulators -- no LDS image, no drain, no flag: stage 2 polls
+        // the data.  Layout [cluster][slice][row pair][col][2 rows]: a lane (col jl, group g) holds rows 4 g .. 4 g + 3 of its column = two
+        // 16-byte stores, 16 lanes = 256 contiguous bytes
+        const unsigned pslice = (unsigned)(((size_t)bh * CL + j) * (LP >> 1) * NQ * 16);
 #pragma unroll
         for (int u = 0; u < MAXT; ++u) {
             const int tl = wave + 8 * u;
             if (tl < ntile) {
                 const int rt = tl / NCT, ct = tl - rt * NCT;
-                // D lane (col jl, group g) reg rr = row 4 g + rr
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) img[(16 * rt + 4 * g + rr) * IS + 16 * ct + jl] = tacc[u][rr];
+                const unsigned o = pslice + (unsigned)((8 * rt + 2 * g) * NQ + 16 * ct + jl) * 16u;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(tacc[u][0]), epoch, __float_as_uint(tacc[u][1]), epoch}, prs, o, 0, BLK_SC);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(tacc[u][2]), epoch, __float_as_uint(tacc[u][3]), epoch}, prs, o + (unsigned)NQ * 16u, 0, BLK_SC);
             }
-        }
-        __syncthreads();
-        float* const part = a.part + ((size_t)bh * CL + j) * L * NQ;
-        for (int e = tid; e < L * (NQ / 4); e += BLK_NTH) {
-            const int row = e / (NQ / 4), q4 = e - row * (NQ / 4);
-            blk_park_quad(part + (size_t)row * NQ + 4 * q4, *reinterpret_cast<const f32x4*>(img + row * IS + 4 * q4));
         }
     }
     BLK_STAMP(4);
-    blk_handoff(cnt, a.cl_shift, a.fault, tid);
     BLK_STAMP(5);
     // =========================================================================================================== stage 2
-    // this workgroup's rows of the head's q | k | v: the CL partials in slice order + bias
+    // this workgroup's row pairs of the head's q | k | v: the CL partials in slice order + bias -> granules tagged with the launch's epoch.
+    // thread -> (row pair, column): one 16-byte load per slice (2 rows of its column), polled until every slice's tag is this launch's
     {
-        const int rows_per = a.rows_per, row0 = j * rows_per;
-        const float* const pbase = a.part + (size_t)bh * CL * L * NQ;
-        float* const qkv = a.qkv + (size_t)bh * L * NQ;
-        for (int e = tid; e < rows_per * (NQ / 4); e += BLK_NTH) {
-            const int rr = e / (NQ / 4), q4 = e - rr * (NQ / 4);
-            const int row = row0 + rr;
-            if (row >= L) continue;
-            f32x4 t[16];
+        const int pp = a.rows_per >> 1, pr0 = j * pp;
+        const unsigned pb = (unsigned)((size_t)bh * CL * (LP >> 1) * NQ * 16);
+        const unsigned gb = (unsigned)((size_t)bh * L * NQ * 8);
+        for (int e = tid; e < pp * NQ; e += BLK_NTH) {
+            const int prl = e / NQ, col = e - prl * NQ;
+            const int pr = pr0 + prl;
+            if (2 * pr >= L) continue;
+            const unsigned o = pb + (unsigned)(pr * NQ + col) * 16u;
+            const unsigned sstride = (unsigned)((LP >> 1) * NQ) * 16u;
+            u32x4 t[16];
+            int tries = 0;
+            for (;;) {
+                bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t[k] = blk_fetch_quad(pbase + ((size_t)(k < CL ? k : 0) * L + row) * NQ + 4 * q4);
-            f32x4 v = t[0];
+                for (int k = 0; k < 16; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b128(prs, o + (unsigned)(k < CL ? k : 0) * sstride, 0, BLK_SC);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ok = ok && t[k][1] == epoch && t[k][3] == epoch;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++tries > BLK_MAX_RETRY) { __hip_atomic_store(a.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+            float v0 = __uint_as_float(t[0][0]), v1 = __uint_as_float(t[0][2]);
 #pragma unroll
             for (int k = 1; k < 16; ++k)
-                if (k < CL) v += t[k];                                     // slice order
-            v += *reinterpret_cast<const f32x4*>(a.bq + h * NQ + 4 * q4);
-            blk_park_quad(qkv + (size_t)row * NQ + 4 * q4, v);
+                if (k < CL) { v0 += __uint_as_float(t[k][0]); v1 += __uint_as_float(t[k][2]); }     // slice order
+            const float bias = a.bq[h * NQ + col];
+            blk_gu64* dst = (blk_gu64*)(unsigned long long)(reinterpret_cast<char*>(a.qkv) + gb + (size_t)((2 * pr) * NQ + col) * 8);
+            __hip_atomic_store(dst, ((unsigned long long)epoch << 32) | __float_as_uint(v0 + bias), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (2 * pr + 1 < L)
+                __hip_atomic_store(dst + NQ, ((unsigned long long)epoch << 32) | __float_as_uint(v1 + bias), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     BLK_STAMP(6);
-    blk_handoff(cnt + 1, a.cl_shift, a.fault, tid);
+    __syncthreads();                                                      // (stage 3 reuses the LDS the GEMM of stage 1 read from)
     BLK_STAMP(7);
     // =========================================================================================================== stage 3
     float* const Ks = smem + lp.ks;
@@ -382,7 +430,18 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     float* const ml = smem + lp.ml;
     float* const po = smem + lp.po;
     const int VSTR = LP + 4, POS = a.ncols + 4;
-    const float* const qkvh = a.qkv + (size_t)bh * L * NQ;
+    const unsigned gbh = (unsigned)((size_t)bh * L * NQ * 8);           // byte offset of this head's granules
+    // one quad (4 granules) of the head's q | k | v rows, polled until this launch's stage 2 has written it
+    auto fetch = [&](int row, int col) -> f32x4 {
+        f32x4 v;
+        const unsigned off = gbh + (unsigned)(row * NQ + col) * 8u;
+        int tries = 0;
+        while (!blk_get_granules(qrs, off, epoch, &v)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++tries > BLK_MAX_RETRY) { __hip_atomic_store(a.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+        return v;
+    };
     for (int it = j; it < nitems; it += CL) {
         const int qt = it % a.nqt, cp = it / a.nqt;
         const int q0 = 16 * qt;
@@ -413,9 +472,8 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
             const int key = e / QPR, kq = e - key * QPR;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
             if (key < nk) {
-                const float* p = qkvh + (size_t)(k0 + key) * NQ + D + 4 * kq;
-                kv = blk_fetch_quad(p) * a.scale;
-                vv = blk_fetch_quad(p + D);
+                kv = fetch(k0 + key, D + 4 * kq) * a.scale;
+                vv = fetch(k0 + key, 2 * D + 4 * kq);
             }
             *reinterpret_cast<f32x4*>(Ks + key * KSTR + 4 * kq) = kv;
 #pragma unroll
@@ -425,7 +483,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
             const int qr = tid / QPR, kq = tid - qr * QPR;
             const int tok = q0 + qr;
             f32x4 qv = {0.f, 0.f, 0.f, 0.f};
-            if (tok < L) qv = blk_fetch_quad(qkvh + (size_t)tok * NQ + 4 * kq) * (a.scale * LOG2E);
+            if (tok < L) qv = fetch(tok, 4 * kq) * (a.scale * LOG2E);
             *reinterpret_cast<f32x4*>(Qs + qr * KSTR + 4 * kq) = qv;
         }
         __syncthreads();
@@ -582,12 +640,12 @@ bool deep_block_configure(DeepBlockArgs& a, int force_cl) {
     a.ncp = best > nqt ? best / nqt : 1;
     while (a.C / a.ncp > 256) a.ncp *= 2;
     a.ncols = a.C / a.ncp;
-    a.rows_per = (a.L + best - 1) / best;
+    a.rows_per = 2 * (((a.L + 15) / 16 * 8 + best - 1) / best);          // row PAIRS are dealt to the workgroups
     return true;
 }
 
-size_t deep_block_part_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.CL * a.L * 3 * a.C; }
-size_t deep_block_qkv_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.L * 3 * a.C; }
+size_t deep_block_part_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.CL * ((a.L + 15) / 16 * 16) * 3 * a.C * 2; }   // 8-byte {data, tag} granules, rows padded to 16
+size_t deep_block_qkv_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.L * 3 * a.C * 2; }     // 8-byte {data, tag} granules
 
 hipError_t launch_deep_block(const DeepBlockArgs& a0, hipStream_t s) {
     DeepBlockArgs a = a0;
@@ -595,6 +653,8 @@ hipError_t launch_deep_block(const DeepBlockArgs& a0, hipStream_t s) {
     if (a.CL < 1 || (a.CL & (a.CL - 1)) || a.CL > 16 || a.CS * a.CL != a.C || a.CS < 16 || a.CS > 64) return hipErrorInvalidValue;
     if ((long)a.B * a.H * a.CL > 128 || a.ncols > 256 || (a.ncols & 15) || a.ncols * a.ncp != a.C) return hipErrorInvalidValue;
     if (!a.part || !a.qkv || !a.cnt || !a.fault || !a.x.p || !a.out) return hipErrorInvalidValue;
+    a.part_bytes = (unsigned)(deep_block_part_floats(a) * 4);
+    a.qkv_bytes = (unsigned)(deep_block_qkv_floats(a) * 4);
     a.cl_shift = __builtin_ctz(a.CL);
     a.qw_shift = __builtin_ctz(a.CS / 4);
     {

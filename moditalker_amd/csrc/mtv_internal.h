@@ -353,13 +353,14 @@ struct DeepBlockArgs {
     unsigned out_slab_stride;
     int CL, CS;              // workgroups per cluster = K slices of the qkv GEMM; channels per slice = C / CL
     float* part;             // scratch [B H][CL][L][3d]: partial qkv of the K slices
-    float* qkv;              // scratch [B H][L][3d]: the head's q | k | v rows (bias added)
-    unsigned long long* cnt; // [B H][2] monotonic arrival counters of the two hand-offs (never reset)
+    float* qkv;              // scratch [B H][L][3d] 8-byte {value, epoch tag} granules: the head's q | k | v rows (bias added)
+    unsigned long long* cnt; // [B H][2] monotonic counters (never reset): [0] arrivals of hand-off 1, [1] entry tickets (-> the launch's epoch)
     int* fault;              // set when a hand-off wait timed out
     int rows_per;            // stage 2: rows a workgroup reduces = ceil(L / CL)
     int nqt, ncp, ncols;     // stage 3: query tiles, column parts, columns per part (C / ncp <= 256)
     // ---- derived by launch_deep_block
     int cl_shift, qw_shift;  // log2(CL), log2(CS / 4)
+    unsigned part_bytes, qkv_bytes;   // sizes of the two scratch buffers (buffer descriptors)
     double inv_n[4];         // 1 / (tokens x gs) of plane 0, 1, 2 and of all planes together
     unsigned long long* dbg; // -DMTV_DEEP_STAMP builds: phase timestamps, else unused
 };

@@ -763,18 +763,26 @@ struct Builder {
             ba.gamma = gw; ba.beta = gb; ba.gs = C / 32;
             ba.Wq = Wq_nk; ba.bq = bq; ba.Wp = Wp_nk; ba.bp = bp;
             static const int force_cl = []() { const char* e = getenv("MTV_BLOCK_CL"); return e ? atoi(e) : 0; }();
-            if (deep_block_configure(ba, force_cl) || (force_cl && deep_block_configure(ba, 0))) {
+            // Where it pays (profiles/r05_deep_block.txt: the block in one launch against fin + qkv + k_deep_attn of round 4, same graph
+            // chains): 32 tokens 15.7 us against 21.1, [128 x 256] 21.2 against 26.8 -- but [128 x 512] 33 against 27.5: there the K slices'
+            // partial q | k | v rows are 12.6 MB of hand-off traffic per block.  MTV_BLOCK_MAX_L / MTV_BLOCK_MAX_LC override the rule.
+            static const int max_l = []() { const char* e = getenv("MTV_BLOCK_MAX_L"); return e ? atoi(e) : 32; }();
+            static const long max_lc = []() { const char* e = getenv("MTV_BLOCK_MAX_LC"); return e ? atol(e) : 128L * 256; }();
+            const bool pays = L.L <= max_l || (long)L.L * C <= max_lc || deep_opt(MTV_DEEP_OPT_BLOCK_ALL, "MTV_DEEP_BLOCK_ALL", false);
+            if (pays && (deep_block_configure(ba, force_cl) || (force_cl && deep_block_configure(ba, 0)))) {
                 Tens out;
                 out.lvl = lvl; out.C = C; out.ks = H;
                 out.slab = (unsigned)((size_t)deep_clips() * L.L * C);
                 out.p = c->buf("act.deep." + nm + ".out", (size_t)8 * out.slab);
-                // scratch shared by every block of the context that needs the same size (the launches of a plan are serial)
+                // Scratch and counters belong to THIS op (the same op of the context's other plans -- forward / step parities -- shares them:
+                // launches are serial).  Never shared between ops: a granule is valid when its tag equals the reader's epoch, and two ops
+                // count their epochs separately -- in a shared buffer op B would accept what op A wrote at the same count.
+                const std::string okey = nm + ".B" + std::to_string(B) + ".CL" + std::to_string(ba.CL);
                 const size_t pf = deep_block_part_floats(ba), qf = deep_block_qkv_floats(ba);
-                ba.part = c->buf("deep.block.part." + std::to_string(pf), pf);
-                ba.qkv = c->buf("deep.block.qkv." + std::to_string(qf), qf);
-                // arrival counters: 64-bit, monotonic (never reset), one pair per (clip, head) of THIS op: plans of different batch sizes
-                // cut clusters differently
-                ba.cnt = reinterpret_cast<unsigned long long*>(c->buf("deep.block.cnt." + nm + ".B" + std::to_string(B) + ".CL" + std::to_string(ba.CL), (size_t)B * H * 2 * 2));
+                ba.part = c->buf("deep.block.part." + okey, pf);
+                ba.qkv = c->buf("deep.block.qkv." + okey, qf);
+                // entry tickets: 64-bit, monotonic (never reset), per (clip, head)
+                ba.cnt = reinterpret_cast<unsigned long long*>(c->buf("deep.block.cnt." + okey, (size_t)B * H * 2 * 2));
                 ba.fault = c->fault_d;
                 ba.out = out.p;
                 ba.out_slab_stride = out.slab;
@@ -2099,7 +2107,7 @@ int mtv_debug_deep(int mode) {
 }
 
 int mtv_debug_deep_options(int mask) {
-    if (mask < -1 || mask > 31) return fail(MTV_ERR_INVALID, "mask must be -1 (environment / defaults) or a combination of MTV_DEEP_OPT_*");
+    if (mask < -1 || mask > 63) return fail(MTV_ERR_INVALID, "mask must be -1 (environment / defaults) or a combination of MTV_DEEP_OPT_*");
     g_deep_opts = mask;
     return MTV_OK;
 }

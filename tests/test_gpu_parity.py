@@ -514,9 +514,11 @@ def _base_eps_and_sample(lib, names_out=None):
 
 
 def test_deep_levels_are_on_by_default_and_off_keeps_the_k_conv_path_green():
-    """Default plan of the base UNet at one clip: the convs of levels 2 / 3 (<= 128 tokens) run on k_deep_conv and each of their 18
-    attention blocks is ONE launch of k_deep_block (csrc/block.hip: no finalize pass, no qkv launch); MTV_DEEP_OPT_NO_BLOCK selects
-    round 4's three launches per block; mtv_debug_deep(0) puts every conv back on k_conv.  All against the reference golden."""
+    """Default plan of the base UNet at one clip: the convs of levels 2 / 3 (<= 128 tokens) run on k_deep_conv; of their 18 attention
+    blocks the 8 where it measures faster (32 tokens, and [128 x 256]) are ONE launch of k_deep_block (csrc/block.hip: no finalize
+    pass, no qkv launch), the other 10 keep round 4's finalize + qkv + fused k_deep_attn; MTV_DEEP_OPT_NO_BLOCK selects the three
+    launches everywhere, MTV_BLOCK_MAX_L=128 the one-launch block everywhere; mtv_debug_deep(0) puts every conv back on k_conv.
+    All against the reference golden."""
     from moditalker_amd import _lib
     lib = _lib.load()
     names = []
@@ -524,8 +526,8 @@ def test_deep_levels_are_on_by_default_and_off_keeps_the_k_conv_path_green():
     assert e1 <= FWD_TOL and s1 <= SAMPLE_TOL, (e1, s1)
     deep = [n for n in names if n.startswith("conv") and " d" in n.split("[")[-1]]
     blocks = [n for n in names if n.startswith("attn") and " blk " in n]
-    fins = [n for n in names if n.startswith("fin")]
-    assert len(deep) >= 28 and len(blocks) == 18 and len(fins) <= 4 and len(names) <= 150, (len(deep), len(blocks), len(fins), len(names))
+    fused = [n for n in names if n.startswith("attn") and "+proj" in n]
+    assert len(deep) >= 28 and len(blocks) == 8 and len(fused) == 10 and len(names) <= 170, (len(deep), len(blocks), len(fused), len(names))
     _lib.check(lib.mtv_debug_deep_options(16), "mtv_debug_deep_options")
     try:
         names = []
@@ -544,11 +546,13 @@ def test_deep_levels_are_on_by_default_and_off_keeps_the_k_conv_path_green():
         lib.mtv_debug_deep(-1)
 
 
-@pytest.mark.parametrize("mask", [1, 2, 4, 8, 9])
+@pytest.mark.parametrize("mask", [1, 2, 4, 8, 9, 16, 32])
 def test_deep_level_dataflow_variants_vs_reference_golden(mask):
     """include/mtv_hip.h MTV_DEEP_OPT_*: in-launch completion (slab + ticket) instead of finalize passes, K-sliced / un-sliced qkv on
-    k_deep_conv, k_attention + proj conv instead of the fused kernel -- eps at three timesteps and a 4-step sample vs the
-    reference golden, and two forwards bit-equal (the completion order of the K slices must not matter)."""
+    k_deep_conv, k_attention + proj conv instead of the fused kernel, the three-launch attention block everywhere (16), the one-launch
+    k_deep_block everywhere (32: also the [128 x 512] blocks the default leaves on three launches) -- eps at three timesteps and a
+    4-step sample vs the reference golden, and repeated forwards bit-equal (the arrival order of K slices / cluster workgroups must not
+    matter, and no hand-off may ever deliver a stale granule)."""
     from moditalker_amd import _lib
     lib = _lib.load()
     _lib.check(lib.mtv_debug_deep_options(mask), "mtv_debug_deep_options")

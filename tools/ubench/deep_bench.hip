@@ -520,7 +520,7 @@ static int run_block(int r, int t, int C, int H, int whole, int x_ks, int B, int
                 for (int c = 0; c < C; ++c) o += xn[(size_t)tk * C + c] * Wq[(size_t)n * C + c];
                 qkv[(size_t)tk * 3 * C + n] = o;
                 const int hh = n / (3 * d), col = n - hh * 3 * d;
-                const float gv = gq[(((size_t)b * H + hh) * L + tk) * 3 * d + col];
+                const float gv = gq[((((size_t)b * H + hh) * L + tk) * 3 * d + col) * 2];      // (8-byte {value, tag} granules)
                 if (gv != gv) nan = true;
                 worst_q = std::max(worst_q, fabs((double)gv - o));
             }
