@@ -188,14 +188,17 @@ int mtv_debug_deep(int mode);
  *                               change the block's dataflow (they describe the three-launch form);
  *   MTV_DEEP_OPT_BLOCK_ALL      k_deep_block for EVERY attention block of the deep levels it can run, not only where it measures faster
  *                               (by default: 32-token blocks and [128 x 256]; at [128 x 512] the three-launch form is faster);
- * -1 = back to the defaults / the MTV_DEEP_INLAUNCH, MTV_DEEP_QKV, MTV_DEEP_QKV1, MTV_DEEP_NO_ATTN, MTV_DEEP_NO_BLOCK, MTV_DEEP_BLOCK_ALL
- * environment variables. */
+ *   MTV_DEEP_OPT_FIN_PASS       a separate k_deep_finalize pass (round 4's default) wherever a consumer needs a deep tensor as ONE plain
+ *                               tensor, instead of round 5's completion inside the producing kernel by data-tagged granules;
+ * -1 = back to the defaults / the MTV_DEEP_INLAUNCH, MTV_DEEP_QKV, MTV_DEEP_QKV1, MTV_DEEP_NO_ATTN, MTV_DEEP_NO_BLOCK, MTV_DEEP_BLOCK_ALL,
+ * MTV_DEEP_FIN_PASS environment variables. */
 #define MTV_DEEP_OPT_INLAUNCH 1
 #define MTV_DEEP_OPT_SLICED_QKV 2
 #define MTV_DEEP_OPT_UNSLICED_QKV 4
 #define MTV_DEEP_OPT_NO_FUSED_ATTN 8
 #define MTV_DEEP_OPT_NO_BLOCK 16
 #define MTV_DEEP_OPT_BLOCK_ALL 32
+#define MTV_DEEP_OPT_FIN_PASS 64
 int mtv_debug_deep_options(int mask);
 
 /* 0: replay the step as a hipGraph (default); 1: plain launches (profiling / debugging). */

@@ -232,6 +232,42 @@ __device__ __forceinline__ void deep_fin_flush(const DeepFin& f, float* scratch,
 }
 constexpr int DEEP_FIN_FLOATS = 4 + 2 * 96 * 2 * 2;      // flag + [2 consumers][96][2] doubles
 
+// ---- completion by data-tagged granules (round 5; same transport as block.hip): two 8-byte {value, epoch} granules per 16-byte store / load,
+// cache policy sc0 | sc1 (write-through, L1-bypassing).  No drain, no flag, no ticket wait: the reader polls the data.
+typedef unsigned deep_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int DEEP_SC = 17;
+constexpr int DEEP_MAX_RETRY = 1 << 18;
+__device__ __forceinline__ void deep_put_granules(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, const f32x4& v, unsigned tag) {
+    __builtin_amdgcn_raw_buffer_store_b128(deep_u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag}, rs, byte_off, 0, DEEP_SC);
+    __builtin_amdgcn_raw_buffer_store_b128(deep_u32x4{__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag}, rs, byte_off + 16, 0, DEEP_SC);
+}
+// quad `qoff` (granule index of its first element) of partial slices 1 .. ns - 1, polled until every tag is this launch's, added to v in slice order
+__device__ __forceinline__ void deep_add_granules(__amdgpu_buffer_rsrc_t rs, unsigned qoff, unsigned slice_granules, int ns, unsigned tag, int* fault, f32x4& v) {
+    deep_u32x4 ta[7], tb[7];
+    int tries = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const unsigned o = (qoff + (unsigned)(k < ns - 1 ? k : 0) * slice_granules) * 8u;
+            ta[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, DEEP_SC);
+            tb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16, 0, DEEP_SC);
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (k < ns - 1) ok = ok && ta[k][1] == tag && ta[k][3] == tag && tb[k][1] == tag && tb[k][3] == tag;
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++tries > DEEP_MAX_RETRY) { __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (k < ns - 1) {
+            v[0] += __uint_as_float(ta[k][0]); v[1] += __uint_as_float(ta[k][2]);
+            v[2] += __uint_as_float(tb[k][0]); v[3] += __uint_as_float(tb[k][2]);
+        }
+}
+
 }  // namespace
 
 #ifdef MTV_DEEP_STAMP   // s_memtime of lane 0 of waves 0 and 4 of workgroups 0 and gridDim / 2: [wg][wave][16 slots]
@@ -262,6 +298,11 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
     const int rgb = slot >> a.ks_shift;
     const int rg = rgb & (a.nrg - 1);
     const int b = rgb >> (a.nrg - 1);
+    // tagged completion (DeepFin::tagged): this workgroup's entry ticket -> the launch's epoch; requested first of all, read much later
+    // (NT == 1 tiles only: the 48-column tiles have no registers to spare -- launch_deep_conv rejects the combination)
+    const bool tg = NT == 1 && a.fin.out != nullptr && a.fin.tagged != 0;
+    unsigned long long early = 0;
+    if (tg && tid == 0) early = __hip_atomic_fetch_add(a.fin.ecnt + ((b * a.nrg + rg) * a.tiles_n + j), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // geometry: output level and the level of the tapped source
     const int r = a.r, t = a.t;
     const int b1 = r * r, b2 = b1 + t * r, L = b2 + t * r;
@@ -395,6 +436,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
                 }
         }
     }
+    if (tg && tid == 0) *reinterpret_cast<unsigned*>(smem + a.lds_fin) = (unsigned)(early >> a.ks_shift) + 1u;     // (the ticket returned long ago)
     DEEP_STAMP(2);
     __syncthreads();
     DEEP_STAMP(3);
@@ -566,7 +608,16 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
     }
     __syncthreads();
     float* const outp = a.out + (size_t)s * a.out_slab_stride;
-    const bool fin = a.fin.out != nullptr;
+    const bool fin = a.fin.out != nullptr && !tg;
+    float* const fscratch = smem + a.lds_fin;
+    const unsigned epoch = tg ? *reinterpret_cast<const unsigned*>(fscratch) : 0u;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(a.fin.gran, 0, tg ? (int)a.fin.gran_bytes : 0, 0x00020000);
+    const unsigned slice_gran = (unsigned)((size_t)a.B * a.Lout * a.N);        // granules per partial slice
+    if (tg && s == 0) {                                   // (uniform) statistics slots of the completing workgroup
+        double* st = reinterpret_cast<double*>(fscratch + 4);
+        for (int e = tid; e < a.fin.nstat * 96 * 2; e += DEEP_NTH) st[e] = 0.0;
+        __syncthreads();
+    }
     for (int e = tid; e < QUADS; e += DEEP_NTH) {
         const int rr = e / QPR, cq = e - rr * QPR;
         if (rr >= rg_ntok) continue;
@@ -575,10 +626,21 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
 #pragma unroll
         for (int w = 1; w < NIMG; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
         if (s == 0) v += (e == tid && pre_ok) ? pre : epi_operands(e);
-        float* dst = outp + ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq;
+        const size_t qoff = ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq;
+        float* dst = outp + qoff;
         if (fin) deep_park_quad(dst, v);
-        else *reinterpret_cast<f32x4*>(dst) = v;
+        else *reinterpret_cast<f32x4*>(dst) = v;          // (tagged completion too: consumers emitted before the plain copy was asked for read the slabs)
+        if (tg) {
+            if (s) {
+                deep_put_granules(grs, (unsigned)(((size_t)(s - 1) * slice_gran + qoff) * 8), v, epoch);
+            } else {
+                deep_add_granules(grs, (unsigned)qoff, slice_gran, a.KS, epoch, a.fin.fault, v);      // slices 1 .. KS - 1, slice order
+                *reinterpret_cast<f32x4*>(a.fin.out + qoff) = v;
+                deep_fin_stat(a.fin, fscratch, rg_tok0 + rr, n0 + 4 * cq, v);
+            }
+        }
     }
+    if (tg && s == 0) deep_fin_flush(a.fin, fscratch, b, tid);
     if (fin) {
         // ---- in-launch completion: the K slice that arrives last turns the tile's slabs into the plain tensor (+ statistics)
         float* scratch = smem + a.lds_fin;
@@ -713,6 +775,10 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     const int qg = rest % a.nqg, b = rest / a.nqg;
     const int q0 = qg * 32;
     const int L = a.L, C = a.C, HPW = a.HPW, NC = a.NC;
+    // tagged completion over the head groups (DeepFin::tagged): entry ticket -> the launch's epoch
+    const bool tg = a.fin.out != nullptr && a.fin.tagged != 0;
+    unsigned long long early = 0;
+    if (tg && tid == 0) early = __hip_atomic_fetch_add(a.fin.ecnt + ((b * a.nqg + qg) * a.ncg + cg), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int b1 = a.r * a.r, b2 = b1 + a.t * a.r;
     // keys this query group can see: all (whole) or the planes its queries live in
     int k0 = 0, k1 = L;
@@ -929,8 +995,17 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) pp[rr * 20] = pacc[rr];
     }
+    float* const fscratch = Os + 8 * 16 * 20;                // past the proj partials (the key-part partials that lay here are dead)
+    if (tg && tid == 0) *reinterpret_cast<unsigned*>(fscratch) = (unsigned)(early >> __builtin_ctz(a.nhg)) + 1u;
+    if (tg && hg == 0) {
+        double* st = reinterpret_cast<double*>(fscratch + 4);
+        for (int e = tid; e < a.fin.nstat * 96 * 2; e += DEEP_NTH) st[e] = 0.0;
+    }
     __syncthreads();
     DEEP_STAMP(7);
+    const unsigned epoch = tg ? *reinterpret_cast<const unsigned*>(fscratch) : 0u;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(a.fin.gran, 0, tg ? (int)a.fin.gran_bytes : 0, 0x00020000);
+    const unsigned slice_gran = (unsigned)((size_t)a.B * L * C);
     // epilogue: thread -> (row, column quad); K parts summed in order; head group 0 adds bias + residual
     for (int e = tid; e < 32 * (NC >> 2); e += DEEP_NTH) {
         const int rr = e / (NC >> 2), cq = e - rr * (NC >> 2);
@@ -945,11 +1020,22 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
             v += pre_b + pre_r;
             for (int k2 = 1; k2 < a.res.ks; ++k2) v += *reinterpret_cast<const f32x4*>(a.res.p + (size_t)k2 * a.res.slab_stride + ((size_t)b * L + tok) * a.res.C + n);
         }
-        float* dst = a.out + (size_t)hg * a.out_slab_stride + ((size_t)b * L + tok) * C + n;
-        if (a.fin.out) deep_park_quad(dst, v);
+        const size_t qoff = ((size_t)b * L + tok) * C + n;
+        float* dst = a.out + (size_t)hg * a.out_slab_stride + qoff;
+        if (a.fin.out && !tg) deep_park_quad(dst, v);
         else *reinterpret_cast<f32x4*>(dst) = v;
+        if (tg) {
+            if (hg) {
+                deep_put_granules(grs, (unsigned)(((size_t)(hg - 1) * slice_gran + qoff) * 8), v, epoch);
+            } else {
+                deep_add_granules(grs, (unsigned)qoff, slice_gran, a.nhg, epoch, a.fin.fault, v);
+                *reinterpret_cast<f32x4*>(a.fin.out + qoff) = v;
+                deep_fin_stat(a.fin, fscratch, tok, n, v);
+            }
+        }
     }
-    if (a.fin.out) {
+    if (tg && hg == 0) deep_fin_flush(a.fin, fscratch, b, tid);
+    if (a.fin.out && !tg) {
         // ---- in-launch completion over the head groups (the K slices of the projection)
         float* scratch = Os + 8 * 16 * 20;                       // past the proj partials
         if (deep_fin_arrive(a.fin, (b * a.nqg + qg) * a.ncg + cg, a.nhg, scratch, tid)) {
@@ -1757,6 +1843,7 @@ hipError_t launch_deep_conv(const DeepArgs& a0, DeepTile t, hipStream_t s) {
     if (a.gn && ((a.gs & 3) || (a.gs & (a.gs - 1)) || a.CSm % a.gs || a.CSm / a.gs > DEEP_MAX_NG)) return hipErrorInvalidValue;
     if (a.N % (16 * t.NT) || (a.N & 3)) return hipErrorInvalidValue;
     if (a.gn && a.whole && a.nrg != 1) return hipErrorInvalidValue;      // statistics over all planes need all planes in one workgroup
+    if (a.fin.out && a.fin.tagged && (t.NT != 1 || !a.fin.gran || !a.fin.ecnt || !a.fin.fault || a.KS < 2 || a.KS > 8)) return hipErrorInvalidValue;
     if (!a.zeros || !a.rowtab) return hipErrorInvalidValue;
     if (!a.gn) { a.gamma = a.beta = a.zeros; }                           // (the kernel loads these vectors unconditionally)
     if (!a.gn || !a.film) { a.film = a.zeros; a.film_stride = 0; }

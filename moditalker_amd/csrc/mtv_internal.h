@@ -126,7 +126,7 @@ struct ConvArgs {
 #if defined(__HIPCC__)
 template <int BYTES>
 __device__ __forceinline__ void touch_kernargs() {
-    static_assert(BYTES <= 8 * 64, "argument block larger than 8 lines");
+    static_assert(BYTES <= 10 * 64, "argument block larger than 10 lines");
     typedef const __attribute__((address_space(4))) void* kptr;
     kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
     // written out in assembly so that the loads stay together, first, with ONE wait (left to the scheduler they
@@ -145,8 +145,18 @@ __device__ __forceinline__ void touch_kernargs() {
         "s_waitcnt lgkmcnt(0)"
         : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
         : "s"(ka), "n"(BYTES > 64 ? 64 : LAST), "n"(BYTES > 128 ? 128 : LAST), "n"(BYTES > 192 ? 192 : LAST),
-          "n"(BYTES > 256 ? 256 : LAST), "n"(BYTES > 320 ? 320 : LAST), "n"(BYTES > 384 ? 384 : LAST), "n"(LAST)
+          "n"(BYTES > 256 ? 256 : LAST), "n"(BYTES > 320 ? 320 : LAST), "n"(BYTES > 384 ? 384 : LAST), "n"(BYTES > 448 ? 448 : LAST)
         : "memory");
+    if constexpr (BYTES > 512) {                 // (round 5: DeepArgs outgrew eight lines)
+        unsigned t8, t9;
+        asm volatile(
+            "s_load_dword %0, %2, %3\n\t"
+            "s_load_dword %1, %2, %4\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&s"(t8), "=&s"(t9)
+            : "s"(ka), "n"(512), "n"(BYTES > 576 ? 576 : LAST)
+            : "memory");
+    }
     __builtin_amdgcn_sched_barrier(0);           // nothing (in particular no argument load) is scheduled above this
 }
 #endif
@@ -255,6 +265,14 @@ struct DeepFin {
     int nstat;
     unsigned stat_cstride;
     SegInfo seg;             // plane boundaries of the output level
+    // ---- round 5: completion by data-tagged granules instead of drain + ticket + re-read (MI355X_MICROARCH.md hand-off price list):
+    // every workgroup of a tile takes an entry ticket (-> the launch's epoch); K slices 1 .. KS-1 also write their partial quads as
+    // 8-byte {value, epoch} granules; slice 0 polls them, adds them in slice order to its own tile and writes the plain tensor + statistics
+    int tagged;              // 1: this form (tickets / parked slabs unused)
+    float* gran;             // [slices - 1][B][L][N] granules (8 bytes each)
+    unsigned gran_bytes;
+    unsigned long long* ecnt;   // [tiles] monotonic entry-ticket counters (never reset)
+    int* fault;              // raised when a poll times out
 };
 
 struct DeepArgs {

@@ -407,23 +407,46 @@ struct Builder {
         // emitted so far keep reading the slabs) -- parity-green, and measured no faster: the store -> drain -> ticket -> re-read
         // chain adds 4-4.5 us to the producing launch (conv3 at 32 tokens 8.3 -> 10.1 us, at 128 tokens 15.1 -> 17.1, the
         // attention block 10.6 -> 14.8), the same three dependent round trips as k_conv's split-K completion.
-        const bool fin_launch = !deep_opt(MTV_DEEP_OPT_INLAUNCH, "MTV_DEEP_INLAUNCH", false);
+        // Round 5 default: completion inside the producing kernel by data-tagged granules (DeepFin::tagged: no drain, no ticket wait -- K slice 0
+        // polls the other slices' partial tiles; profiles/r05_tagged_fin_ab.txt).  MTV_DEEP_FIN_PASS=1 / MTV_DEEP_OPT_FIN_PASS: round 4's pass.
+        const bool ticket_inlaunch = deep_opt(MTV_DEEP_OPT_INLAUNCH, "MTV_DEEP_INLAUNCH", false);
+        const bool tagged_inlaunch = !ticket_inlaunch && !deep_opt(MTV_DEEP_OPT_FIN_PASS, "MTV_DEEP_FIN_PASS", false);
         DeepFin* fn = nullptr;
         std::shared_ptr<void> owner;
-        long ntile = 0;
-        if (!fin_launch) {
+        long ntile = 0, nwg = 0;
+        int nslices = 0, lastN = 0;
+        bool tile_ok = true;
+        if (ticket_inlaunch || tagged_inlaunch) {
             auto dp = deep_producer.find(x.p);
             auto ap = attn_producer.find(x.p);
-            if (dp != deep_producer.end()) { fn = &dp->second->a.fin; owner = dp->second; ntile = (long)B * dp->second->a.nrg * dp->second->a.tiles_n; }
-            else if (ap != attn_producer.end()) { fn = &ap->second->a.fin; owner = ap->second; ntile = (long)B * ap->second->a.nqg * ap->second->a.ncg; }
+            if (dp != deep_producer.end()) {
+                fn = &dp->second->a.fin; owner = dp->second; ntile = (long)B * dp->second->a.nrg * dp->second->a.tiles_n;
+                nslices = dp->second->a.KS; nwg = ntile * nslices; lastN = dp->second->a.N; tile_ok = dp->second->t.NT == 1;
+            } else if (ap != attn_producer.end()) {
+                fn = &ap->second->a.fin; owner = ap->second; ntile = (long)B * ap->second->a.nqg * ap->second->a.ncg;
+                nslices = ap->second->a.nhg; nwg = ntile * nslices; lastN = ap->second->a.C;
+            }
+            // (the polling slice waits for workgroups of the same launch: all of them must be resident together)
+            if (fn && tagged_inlaunch && (!tile_ok || nwg > 256 || nslices < 2 || nslices > 8)) fn = nullptr;
         }
         if (fn) {
             fn->out = o.p;
-            fn->tickets = reinterpret_cast<int*>(c->buf("deep.tickets." + name + ".B" + std::to_string(B), (size_t)ntile));
             fn->nstat = 0;
             fn->stat_cstride = (unsigned)c->stats_copy_doubles;
             fn->seg = c->lv[x.lvl].seg();
-            if (!fn->tickets) { err = "ticket allocation failed at " + name; return Tens{}; }
+            if (tagged_inlaunch) {
+                const size_t gf = (size_t)(nslices - 1) * B * c->lv[x.lvl].L * lastN * 2;        // 8-byte granules
+                const std::string okey = name + ".B" + std::to_string(B) + ".S" + std::to_string(nslices);
+                fn->tagged = 1;
+                fn->gran = c->buf("deep.fin.gran." + okey, gf);                                  // (per op: tags are only unique per counter)
+                fn->gran_bytes = (unsigned)(gf * 4);
+                fn->ecnt = reinterpret_cast<unsigned long long*>(c->buf("deep.fin.ecnt." + okey, (size_t)ntile * 2));
+                fn->fault = c->fault_d;
+                if (!fn->gran || !fn->ecnt || !fn->fault) { err = "granule scratch allocation failed at " + name; return Tens{}; }
+            } else {
+                fn->tickets = reinterpret_cast<int*>(c->buf("deep.tickets." + name + ".B" + std::to_string(B), (size_t)ntile));
+                if (!fn->tickets) { err = "ticket allocation failed at " + name; return Tens{}; }
+            }
             fin_producer[o.p] = StatSink{fn->stat, &fn->nstat, owner};
             fin_cache[x.p] = o;
             return o;
@@ -2107,7 +2130,7 @@ int mtv_debug_deep(int mode) {
 }
 
 int mtv_debug_deep_options(int mask) {
-    if (mask < -1 || mask > 63) return fail(MTV_ERR_INVALID, "mask must be -1 (environment / defaults) or a combination of MTV_DEEP_OPT_*");
+    if (mask < -1 || mask > 127) return fail(MTV_ERR_INVALID, "mask must be -1 (environment / defaults) or a combination of MTV_DEEP_OPT_*");
     g_deep_opts = mask;
     return MTV_OK;
 }

@@ -546,11 +546,12 @@ def test_deep_levels_are_on_by_default_and_off_keeps_the_k_conv_path_green():
         lib.mtv_debug_deep(-1)
 
 
-@pytest.mark.parametrize("mask", [1, 2, 4, 8, 9, 16, 32])
+@pytest.mark.parametrize("mask", [1, 2, 4, 8, 9, 16, 32, 64, 80])
 def test_deep_level_dataflow_variants_vs_reference_golden(mask):
     """include/mtv_hip.h MTV_DEEP_OPT_*: in-launch completion (slab + ticket) instead of finalize passes, K-sliced / un-sliced qkv on
     k_deep_conv, k_attention + proj conv instead of the fused kernel, the three-launch attention block everywhere (16), the one-launch
-    k_deep_block everywhere (32: also the [128 x 512] blocks the default leaves on three launches) -- eps at three timesteps and a
+    k_deep_block everywhere (32: also the [128 x 512] blocks the default leaves on three launches), k_deep_finalize passes instead of the
+    default completion by tagged granules inside the producing kernel (64; 80 = round 4's plan: 64 + 16) -- eps at three timesteps and a
     4-step sample vs the reference golden, and repeated forwards bit-equal (the arrival order of K slices / cluster workgroups must not
     matter, and no hand-off may ever deliver a stale granule)."""
     from moditalker_amd import _lib
