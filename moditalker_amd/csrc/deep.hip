@@ -306,7 +306,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
     // geometry: output level and the level of the tapped source
     const int r = a.r, t = a.t;
     const int b1 = r * r, b2 = b1 + t * r, L = b2 + t * r;
-    const int rs = a.up_main ? r >> 1 : r, ts = a.up_main ? t >> 1 : t;
+    const int rs = a.up_main ? r >> 1 : (a.pool_main ? r << 1 : r), ts = a.up_main ? t >> 1 : (a.pool_main ? t << 1 : t);
     const int b1s = rs * rs, b2s = b1s + ts * rs, Ls = b2s + ts * rs;
     const int rg_tok0 = (a.nrg == 2 && rg) ? b1 : 0;
     const int rg_ntok = a.nrg == 2 ? (rg ? L - b1 : b1) : L;
@@ -487,6 +487,29 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
         }
     }
     __syncthreads();
+    if (a.pool_main) {
+        // ResBlock(down=True): the conv reads AvgPool2d(SiLU(GroupNorm(x))) (unet.py:179-184): 2x2 mean, per plane, of the transformed source
+        // rows -> this level's rows, parked behind the source slice; the row table points there.  Sum order as F.avg_pool2d: row-major window.
+        float* const lpool = smem + a.lds_pool;
+        const int RP = DEEP_NTH >> qw_shift;
+        const int qdp = tid & (QWm - 1);
+        for (int ro = tid >> qw_shift; ro <= rg_ntok; ro += RP) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ro < rg_ntok) {
+                const int tok = rg_tok0 + ro;
+                const int p = tok >= b2 ? 2 : (tok >= b1 ? 1 : 0);
+                const int off = p == 0 ? 0 : (p == 1 ? b1 : b2), offs = p == 0 ? 0 : (p == 1 ? b1s : b2s);
+                const int local = tok - off, y = FDiv{a.inv_r}(local, r), x = local - y * r;
+                const int s00 = offs + (2 * y) * rs + 2 * x - src_tok0;
+                const float* c0 = lmain + s00 * SM + 4 * qdp;
+                const f32x4 v00 = *reinterpret_cast<const f32x4*>(c0), v01 = *reinterpret_cast<const f32x4*>(c0 + SM);
+                const f32x4 v10 = *reinterpret_cast<const f32x4*>(c0 + rs * SM), v11 = *reinterpret_cast<const f32x4*>(c0 + rs * SM + SM);
+                v = (((v00 + v01) + v10) + v11) * 0.25f;
+            }
+            *reinterpret_cast<f32x4*>(lpool + ro * SM + 4 * qdp) = v;          // (row rg_ntok = the zero row of the padding taps)
+        }
+        __syncthreads();
+    }
     DEEP_STAMP(4);
     // =========================================================================================================== phase 2
     // epilogue operands of K slice 0 (bias, residual: they depend on nothing computed here) are requested now by every
@@ -500,12 +523,32 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
         f32x4 o = *reinterpret_cast<const f32x4*>(a.bias + n);
         if (a.bias2) o += *reinterpret_cast<const f32x4*>(a.bias2 + n);
         if (a.bias_b) o += *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + n);
-        if (a.res.p) {
+        if (a.res.p && !a.pool_res) {
             const int rtok = a.up_res ? (geo_source_t<FDiv>(FDiv{a.inv_r}, r, t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
             o += slab_sum_rt(a.res.p + ((size_t)b * a.Lres + rtok) * a.res.C + n, a.res.slab_stride, a.res.ks);
         }
         return o;
     };
+    // ResBlock(down=True), identity skip: the residual is AvgPool2d of the raw input (unet.py:182-184).  The mean is linear, so K slice s adds
+    // the pooled source slabs s, s + KS, ... (the consumers add the slices up anyway): four 16-byte loads per slab instead of 4 x ks in slice 0
+    auto pooled_res = [&](int e) -> f32x4 {
+        const int rr = e / QPR, cq = e - rr * QPR;
+        const int tok = rg_tok0 + rr, n = n0 + 4 * cq;
+        const int p = tok >= b2 ? 2 : (tok >= b1 ? 1 : 0);
+        const int rr2 = r << 1, b1f = rr2 * rr2, b2f = b1f + (t << 1) * rr2;
+        const int off = p == 0 ? 0 : (p == 1 ? b1 : b2), offf = p == 0 ? 0 : (p == 1 ? b1f : b2f);
+        const int local = tok - off, y = FDiv{a.inv_r}(local, r), x = local - y * r;
+        const float* base = a.res.p + ((size_t)b * a.Lres + offf + (2 * y) * rr2 + 2 * x) * a.res.C + n;
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        for (int k = s; k < a.res.ks; k += a.KS) {
+            const float* pk = base + (size_t)k * a.res.slab_stride;
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(pk), v01 = *reinterpret_cast<const f32x4*>(pk + a.res.C);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(pk + (size_t)rr2 * a.res.C), v11 = *reinterpret_cast<const f32x4*>(pk + (size_t)(rr2 + 1) * a.res.C);
+            acc4 += (((v00 + v01) + v10) + v11) * 0.25f;
+        }
+        return acc4;
+    };
+    const bool pool_r = a.pool_res != 0 && a.res.p != nullptr && s < a.res.ks;
     const bool pre_ok = s == 0 && tid < QUADS && tid / QPR < rg_ntok;
     if (pre_ok) pre = epi_operands(tid);
 
@@ -626,6 +669,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
 #pragma unroll
         for (int w = 1; w < NIMG; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
         if (s == 0) v += (e == tid && pre_ok) ? pre : epi_operands(e);
+        if (pool_r) v += pooled_res(e);
         const size_t qoff = ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq;
         float* dst = outp + qoff;
         if (fin) deep_park_quad(dst, v);
@@ -1712,7 +1756,7 @@ size_t deep_weight_floats(const DeepArgs& a, int NT) {
 
 static int deep_rows(const DeepArgs& a, int* src_rows) {     // rows of the largest row group: output, tapped source
     const int b1 = a.r * a.r, L = b1 + 2 * a.t * a.r;
-    const int rs = a.up_main ? a.r >> 1 : a.r, ts = a.up_main ? a.t >> 1 : a.t;
+    const int rs = a.up_main ? a.r >> 1 : (a.pool_main ? a.r << 1 : a.r), ts = a.up_main ? a.t >> 1 : (a.pool_main ? a.t << 1 : a.t);
     const int b1s = rs * rs, Ls = b1s + 2 * ts * rs;
     if (a.nrg == 2) {
         *src_rows = b1s > Ls - b1s ? b1s : Ls - b1s;
@@ -1742,11 +1786,16 @@ size_t deep_smem_bytes(const DeepArgs& a0, DeepTile t) {
 }
 static size_t deep_layout(DeepArgs& a, DeepTile t) {
     int srows = 0;
-    (void)deep_rows(a, &srows);
+    const int orows = deep_rows(a, &srows);
     const int ROWS = 16 * t.RT;
     a.src_rows_max = srows;
     const int SM = a.CSm + DEEP_PAD, SS = a.CSs + DEEP_PAD;
     int off = (srows + 1) * SM;
+    a.lds_pool = 0;
+    if (a.pool_main) {                                                      // pooled rows of the largest row group + the zero row
+        a.lds_pool = off;
+        off += (orows + 1) * SM;
+    }
     a.lds_skip = off;
     if (a.Cskip) off += (ROWS + 1) * SS;
     a.lds_idx = off;
@@ -1807,6 +1856,24 @@ std::vector<int> deep_rowtab(const DeepArgs& a0, DeepTile t) {
     for (int rg = 0; rg < a.nrg; ++rg) {
         const int tok0 = (a.nrg == 2 && rg) ? b1 : 0, ntok = a.nrg == 2 ? (rg ? L - b1 : b1) : L;
         const int stok0 = (a.nrg == 2 && rg) ? b1s : 0;
+        if (a.pool_main) {
+            // the taps read the POOLED rows (this level's own grid, row i of the group at lds_pool + i SM; the zero row follows the group)
+            int* tbp = tab.data() + (size_t)rg * (a.ntaps + 1) * ROWS;
+            for (int tap = 0; tap < a.ntaps; ++tap)
+                for (int ri = 0; ri < ROWS; ++ri) {
+                    int row = -1;
+                    if (ri < ntok) {
+                        const int tok = tok0 + ri;
+                        if (a.ntaps == 9) {
+                            const int g = geo_source(r, tt, tok, tap / 3, tap % 3, false);
+                            row = g < 0 ? -1 : (g & 0x0FFFFFFF) - tok0;
+                        } else row = ri;
+                    }
+                    tbp[tap * ROWS + ri] = a.lds_pool + (row < 0 ? ntok : row) * SM;
+                }
+            for (int ri = 0; ri < ROWS; ++ri) tbp[a.ntaps * ROWS + ri] = ri < ntok ? ri * SS : ROWS * SS;
+            continue;
+        }
         int* tb = tab.data() + (size_t)rg * (a.ntaps + 1) * ROWS;
         for (int tap = 0; tap < a.ntaps; ++tap)
             for (int ri = 0; ri < ROWS; ++ri) {
@@ -1845,6 +1912,7 @@ hipError_t launch_deep_conv(const DeepArgs& a0, DeepTile t, hipStream_t s) {
     if (a.gn && a.whole && a.nrg != 1) return hipErrorInvalidValue;      // statistics over all planes need all planes in one workgroup
     if (a.fin.out && a.fin.tagged && (t.NT != 1 || !a.fin.gran || !a.fin.ecnt || !a.fin.fault || a.KS < 2 || a.KS > 8)) return hipErrorInvalidValue;
     if (!a.zeros || !a.rowtab) return hipErrorInvalidValue;
+    if ((a.pool_main && (a.up_main || a.main[1].p)) || (a.pool_res && (a.up_res || !a.res.p))) return hipErrorInvalidValue;
     if (!a.gn) { a.gamma = a.beta = a.zeros; }                           // (the kernel loads these vectors unconditionally)
     if (!a.gn || !a.film) { a.film = a.zeros; a.film_stride = 0; }
     a.tiles_n = a.N / (16 * t.NT);
@@ -1857,7 +1925,7 @@ hipError_t launch_deep_conv(const DeepArgs& a0, DeepTile t, hipStream_t s) {
     a.inv_r = 1.0f / (float)a.r;
     a.inv_rs = 0.f;
     {   // reciprocal element counts of the GroupNorm statistics (source level): planes 0, 1, 2 and all planes together
-        const int rs = a.up_main ? a.r >> 1 : a.r, ts = a.up_main ? a.t >> 1 : a.t;
+        const int rs = a.up_main ? a.r >> 1 : (a.pool_main ? a.r << 1 : a.r), ts = a.up_main ? a.t >> 1 : (a.pool_main ? a.t << 1 : a.t);
         const double gsd = a.gn ? (double)a.gs : 1.0;
         a.inv_n[0] = 1.0 / ((double)rs * rs * gsd);
         a.inv_n[1] = a.inv_n[2] = 1.0 / ((double)ts * rs * gsd);

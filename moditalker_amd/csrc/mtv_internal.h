@@ -282,6 +282,10 @@ struct DeepArgs {
     int Cmain, Cskip;        // channels of the concatenations
     int ntaps;               // 9 (3x3 on the tri-plane grid) or 1
     int up_main, up_res;     // 1: that source lives on the next-coarser level (nearest x2 upsampling folded into the row map)
+    int pool_main, pool_res; // 1: that source lives on the next-FINER level (ResBlock(down=True), unet.py:179-184): pool_main -- GroupNorm / SiLU are
+                             // applied there (once per element, in LDS), then the 2x2 mean per plane (AvgPool2d, unet.py:594) gives this level's rows;
+                             // pool_res -- the residual is the 2x2 mean of the raw source, shared out over the K slices (slice s adds source slabs s, s + KS, ...)
+    int lds_pool;            // LDS offset (floats) of the pooled rows (pool_main; set by the layout)
     int r, t;                // plane geometry of the OUTPUT level: xy r x r | yt t x r | xt t x r
     int B, Lout, Lsrc, Lres; // tokens per clip: output, tapped source, residual source
     int N;                   // output channels (multiple of 16 NT)

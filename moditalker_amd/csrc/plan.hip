@@ -357,7 +357,7 @@ struct Builder {
         a.W = c->wdeep_for(W, ldw, a, t.NT);
         {   // row table: one per (geometry, slicing) -- shared by every conv of the context that has the same
             char key[128];
-            snprintf(key, sizeof key, "deep.rowtab %d %d %d %d %d %d %d %d %d %d", a.r, a.t, a.up_main, a.ntaps, a.nrg, t.RT, a.CSm, a.CSs, a.Cskip ? 1 : 0, a.Lout);
+            snprintf(key, sizeof key, "deep.rowtab %d %d %d %d %d %d %d %d %d %d", a.r, a.t, a.up_main + 2 * a.pool_main, a.ntaps, a.nrg, t.RT, a.CSm, a.CSs, a.Cskip ? 1 : 0, a.Lout);
             if (!c->bufs.count(key)) {
                 const std::vector<int> tab = deep_rowtab(a, t);
                 float* d = c->buf(key, tab.size());
@@ -553,9 +553,19 @@ struct Builder {
         if (deep_on(lvl_out) && !(r.updown == 1 && x.size() != 1) && !(has_skip_conv && r.updown) && (has_skip_conv || x.size() == 1)) {
             // ---- deep level: both convs K-sliced, partial slabs summed by their consumers (deep.hip)
             const bool down = r.updown == 1, up = r.updown == 2;
+            // ResBlock(down=True) (unet.py:179-184, Downsample = AvgPool2d :594): round 5 folds both 2x2 means into the two convs -- conv1
+            // stages the finer level's rows, applies GroupNorm / SiLU there and pools in LDS; conv2's residual is the pooled raw input, shared
+            // out over its K slices.  No k_pool_down launch, no plain copy of the input, no statistics site.  MTV_DEEP_POOL_FOLD=0: round 4's form.
+            static const bool fold_env = []() { const char* e = getenv("MTV_DEEP_POOL_FOLD"); return !e || atoi(e) != 0; }();
+            const bool fold = down && fold_env && x.size() == 1 && !has_skip_conv;
             DeepArgs a1 = deep_args(lvl_out, 9, r.cout, cb1);
             a1.Cmain = cin;
-            if (down) {
+            if (fold) {
+                a1.main[0] = dsrc(x[0]);
+                a1.pool_main = 1;
+                a1.Lsrc = Li.L;
+                a1.gn = 1; a1.act = 1; a1.gs = cin / 32; a1.gamma = g1; a1.beta = b1;
+            } else if (down) {
                 a1.main[0] = DeepSrc{a1.zeros, 0, 1, cin};                 // (placeholder for the pooled, already normalised input)
             } else {
                 for (size_t i = 0; i < x.size(); ++i) a1.main[i] = dsrc(x[i]);
@@ -573,6 +583,10 @@ struct Builder {
                 for (size_t i = 0; i < x.size(); ++i) a2.skip[i] = dsrc(x[i]);
                 a2.Cskip = cin;
                 a2.bias2 = sb;
+            } else if (fold) {
+                a2.res = dsrc(x[0]);
+                a2.pool_res = 1;
+                a2.Lres = Li.L;
             } else if (down) {
                 a2.res = DeepSrc{a2.zeros, 0, 1, r.cout};                  // (placeholder for the pooled x)
             } else {
@@ -582,7 +596,7 @@ struct Builder {
             }
             DeepTile t1{}, t2{};
             if (deep_configure(a1, &t1) && deep_configure(a2, &t2)) {
-                if (down) {
+                if (down && !fold) {
                     const Tens x0 = materialize(x[0], nm + ".x");         // k_pool_down reads a plain tensor + its statistics
                     double* site1 = c->new_site();
                     add_stats({x0}, lvl_in, site1);

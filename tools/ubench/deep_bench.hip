@@ -49,8 +49,16 @@ static DeepSrc make_src(int B, int L, int C, int ks, std::vector<float>& sum) {
 
 static int run_case(const Case& c) {
     const int r = c.r, t = c.t, b1 = r * r, b2 = b1 + t * r, L = b2 + t * r;
-    const int rs = c.up ? r / 2 : r, ts = c.up ? t / 2 : t, b1s = rs * rs, b2s = b1s + ts * rs, Ls = b2s + ts * rs;
-    const int rr = c.up_res ? r / 2 : r, tr = c.up_res ? t / 2 : t, Lr = rr * rr + 2 * tr * rr;
+    // up / up_res: 1 = that source on the next-coarser level (nearest x2), 2 = on the next-FINER level (2x2 mean per plane: ResBlock(down=True))
+    const int rs = c.up == 1 ? r / 2 : (c.up == 2 ? 2 * r : r), ts = c.up == 1 ? t / 2 : (c.up == 2 ? 2 * t : t), b1s = rs * rs, b2s = b1s + ts * rs, Ls = b2s + ts * rs;
+    const int rr = c.up_res == 1 ? r / 2 : (c.up_res == 2 ? 2 * r : r), tr = c.up_res == 1 ? t / 2 : (c.up_res == 2 ? 2 * t : t), Lr = rr * rr + 2 * tr * rr;
+    // the four finer-level tokens under a token of this level (same plane)
+    auto finer4 = [&](int tok, int (&o)[4]) {
+        const int p = tok >= b2 ? 2 : (tok >= b1 ? 1 : 0), off = p == 0 ? 0 : (p == 1 ? b1 : b2);
+        const int r2 = 2 * r, t2 = 2 * t, b1f = r2 * r2, b2f = b1f + t2 * r2, offf = p == 0 ? 0 : (p == 1 ? b1f : b2f);
+        const int y = (tok - off) / r, x = (tok - off) % r;
+        o[0] = offf + 2 * y * r2 + 2 * x; o[1] = o[0] + 1; o[2] = o[0] + r2; o[3] = o[2] + 1;
+    };
     const int Cmain = c.Cm0 + c.Cm1, Cskip = c.Cs0 + c.Cs1, K = c.ntaps * Cmain + Cskip, ldw = (c.N + 63) / 64 * 64;
     DeepArgs a{};
     std::vector<float> xm[2], xs[2], xr;
@@ -59,7 +67,7 @@ static int run_case(const Case& c) {
     if (c.Cs0) a.skip[0] = make_src(c.B, L, c.Cs0, c.ks_in, xs[0]);
     if (c.Cs1) a.skip[1] = make_src(c.B, L, c.Cs1, 1, xs[1]);
     if (c.res) a.res = make_src(c.B, Lr, c.N, c.ks_res, xr);
-    a.Cmain = Cmain; a.Cskip = Cskip; a.ntaps = c.ntaps; a.up_main = c.up; a.up_res = c.up_res; a.r = r; a.t = t;
+    a.Cmain = Cmain; a.Cskip = Cskip; a.ntaps = c.ntaps; a.up_main = c.up == 1; a.up_res = c.up_res == 1; a.pool_main = c.up == 2; a.pool_res = c.up_res == 2; a.r = r; a.t = t;
     a.B = c.B; a.Lout = L; a.Lsrc = Ls; a.Lres = Lr; a.N = c.N;
     std::vector<float> W((size_t)K * ldw), bias(c.N), bias2(c.N), gamma(Cmain), beta(Cmain), film((size_t)c.B * 2 * Cmain);
     const float wsc = 1.0f / sqrtf((float)K);
@@ -127,13 +135,16 @@ static int run_case(const Case& c) {
             for (int tap = 0; tap < c.ntaps; ++tap) {
                 int src;
                 if (c.ntaps == 9) {
-                    const int g = geo_source(r, t, tok, tap / 3, tap % 3, c.up != 0);
+                    const int g = geo_source(r, t, tok, tap / 3, tap % 3, c.up == 1);
                     if (g < 0) continue;
                     src = g & 0x0FFFFFFF;
-                } else src = c.up ? (geo_source(r, t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
-                const float* ar = &act[((size_t)b * Ls + src) * Cmain];
+                } else src = c.up == 1 ? (geo_source(r, t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
+                int f4[4] = {src, src, src, src};
+                if (c.up == 2) finer4(src, f4);                       // the conv reads the 2x2 mean of the transformed finer-level rows
                 for (int ch = 0; ch < Cmain; ++ch) {
-                    const double av = ar[ch];
+                    const double av = c.up == 2 ? 0.25 * ((double)act[((size_t)b * Ls + f4[0]) * Cmain + ch] + act[((size_t)b * Ls + f4[1]) * Cmain + ch] +
+                                                          act[((size_t)b * Ls + f4[2]) * Cmain + ch] + act[((size_t)b * Ls + f4[3]) * Cmain + ch])
+                                                : (double)act[((size_t)b * Ls + src) * Cmain + ch];
                     const float* wr = &W[((size_t)tap * Cmain + ch) * ldw];
                     for (int n = 0; n < c.N; ++n) o[n] += av * wr[n];
                 }
@@ -143,10 +154,14 @@ static int run_case(const Case& c) {
                 const float* wr = &W[((size_t)c.ntaps * Cmain + ch) * ldw];
                 for (int n = 0; n < c.N; ++n) o[n] += av * wr[n];
             }
-            const int rtok = c.up_res ? (geo_source(r, t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
+            const int rtok = c.up_res == 1 ? (geo_source(r, t, tok, 1, 1, true) & 0x0FFFFFFF) : tok;
+            int r4[4] = {rtok, rtok, rtok, rtok};
+            if (c.up_res == 2) finer4(tok, r4);
             for (int n = 0; n < c.N; ++n) {
                 o[n] += bias[n] + (Cskip ? bias2[n] : 0.f);
-                if (c.res) o[n] += xr[((size_t)b * Lr + rtok) * c.N + n];
+                if (c.res) o[n] += c.up_res == 2 ? 0.25 * ((double)xr[((size_t)b * Lr + r4[0]) * c.N + n] + xr[((size_t)b * Lr + r4[1]) * c.N + n] +
+                                                          xr[((size_t)b * Lr + r4[2]) * c.N + n] + xr[((size_t)b * Lr + r4[3]) * c.N + n])
+                                                : (double)xr[((size_t)b * Lr + rtok) * c.N + n];
             }
         }
     double worst = 0.0, scale = 0.0;
@@ -184,6 +199,14 @@ static int do_check() {
         {"full m32 out conv2 k5632",  4, 2, 0, 9, 512,   0, 512, 512, 512, 1, 0, 1, 1, 0, 0, 8, 1, 8, 1, 1},
         {"full m128 k9216 rg2",       8, 4, 0, 9, 512, 512,   0,   0, 512, 1, 0, 1, 0, 0, 0, 4, 1, 4, 2, 1},
         {"full m128 qkv whole",       8, 4, 0, 1, 512,   0,   0,   0, 1536, 1, 1, 0, 0, 0, 0, 4, 1, 8, 1, 1},
+        // ResBlock(down=True): AvgPool2d folded in (up = 2: conv1 reads the pooled, transformed finer level; upr = 2: conv2's residual is the pooled raw input)
+        {"pool m32 conv1 (in9.0.h1)",  4, 2, 2, 9, 512,   0,   0,   0, 512, 1, 0, 1, 0, 0, 0, 4, 1, 8, 1, 1},
+        {"pool m32 conv2 res ks8",     4, 2, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 1, 1, 2, 8, 8, 8, 1, 1},
+        {"pool m32 conv2 res ks4 KS8", 4, 2, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 1, 1, 2, 8, 4, 8, 1, 1},
+        {"pool m128 conv1 rg2 (in6.0)",8, 4, 2, 9, 256,   0,   0,   0, 256, 1, 0, 1, 0, 0, 0, 1, 1, 8, 2, 1},
+        {"pool m128 conv2 res plain",  8, 4, 0, 9, 128,   0,   0,   0, 128, 1, 0, 1, 1, 1, 2, 8, 1, 4, 2, 1},
+        {"pool m128 B2 conv1 rg2",     8, 4, 2, 9, 128,   0,   0,   0, 128, 1, 0, 1, 0, 0, 0, 2, 1, 4, 2, 2},
+        {"pool ragged r6 t3 conv1",    6, 3, 2, 9, 128,   0,   0,   0, 128, 1, 0, 1, 0, 1, 2, 2, 2, 4, 2, 1},
     };
     int bad = 0;
     for (auto& c : cases) bad += run_case(c);
