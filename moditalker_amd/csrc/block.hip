@@ -314,8 +314,15 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
             const int p = row >= b2 ? 2 : (row >= b1 ? 1 : 0);
             if (p != cur_p) {
                 cur_p = p;
+                float mu_w = 0.f, rstd_w = 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    if (k > 0 && (gs & 3) == 0) {                          // the four channels of a quad share their group: one (mean, rstd)
+                        const float sc = rstd_w * ga[k];
+                        A[k] = sc;
+                        Bc[k] = be[k] - sc * mu_w;
+                        continue;
+                    }
                     const int gi = (4 * qd + k) / gs;
                     double sx, sy;
                     if (a.whole) {
@@ -330,6 +337,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
                     double var = sy * inv_n - mean * mean;
                     var = var < 0.0 ? 0.0 : var;
                     const float mu = (float)mean, rstd = 1.0f / sqrtf((float)var + 1e-5f);
+                    mu_w = mu; rstd_w = rstd;
                     const float sc = rstd * ga[k];
                     A[k] = sc;
                     Bc[k] = be[k] - sc * mu;

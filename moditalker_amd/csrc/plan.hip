@@ -557,7 +557,7 @@ struct Builder {
             // stages the finer level's rows, applies GroupNorm / SiLU there and pools in LDS; conv2's residual is the pooled raw input, shared
             // out over its K slices.  No k_pool_down launch, no plain copy of the input, no statistics site.  MTV_DEEP_POOL_FOLD=0: round 4's form.
             static const bool fold_env = []() { const char* e = getenv("MTV_DEEP_POOL_FOLD"); return !e || atoi(e) != 0; }();
-            const bool fold = down && fold_env && x.size() == 1 && !has_skip_conv;
+            const bool fold = down && fold_env && x.size() == 1 && !has_skip_conv && Li.r == 2 * Lo.r && Li.t == 2 * Lo.t;     // (even planes only)
             DeepArgs a1 = deep_args(lvl_out, 9, r.cout, cb1);
             a1.Cmain = cin;
             if (fold) {
@@ -2126,6 +2126,39 @@ int mtv_selftest_deep(int res, int frames, int n_levels) {
                             if (tb[ntaps * ROWS + ri] != (ri < ntok ? ri * SS : ROWS * SS)) return l + 1;
                     }
                 }
+        }
+        // ResBlock(down=True) folded into the conv (DeepArgs::pool_main, round 5): the source lives on level l - 1, the taps read the POOLED
+        // rows of this level's own grid, parked behind the source slice (lds_pool = (source rows of the largest group + 1) SM)
+        if (l > 0) {
+            const Level& src = lv[l - 1];
+            const std::vector<int> g3 = make_gather3(lv[l], lv[l], false);
+            for (int nrg = 1; nrg <= 2; ++nrg) {
+                DeepArgs a{};
+                a.ntaps = 9; a.r = lv[l].r; a.t = lv[l].t; a.pool_main = 1; a.B = 1; a.Lout = lv[l].L; a.Lsrc = src.L;
+                a.N = 64; a.Cmain = 64; a.KS = 1; a.CSm = 64; a.nrg = nrg;
+                if (src.r != 2 * lv[l].r || src.t != 2 * lv[l].t) continue;      // (odd geometries never take the folded path: plan.hip)
+                DeepTile t{};
+                if (!deep_tile_for(a, &t)) return l + 1;
+                const std::vector<int> tab = deep_rowtab(a, t);
+                const int ROWS = 16 * t.RT, SM = a.CSm + 8;
+                int srows = 0;
+                for (int rg = 0; rg < nrg; ++rg) {
+                    const int ssz = nrg == 2 ? (rg ? src.L - src.b1 : src.b1) : src.L;
+                    srows = ssz > srows ? ssz : srows;
+                }
+                const int lds_pool = (srows + 1) * SM;
+                for (int rg = 0; rg < nrg; ++rg) {
+                    const int tok0 = (nrg == 2 && rg) ? lv[l].b1 : 0, ntok = nrg == 2 ? (rg ? lv[l].L - lv[l].b1 : lv[l].b1) : lv[l].L;
+                    const int* tb = tab.data() + (size_t)rg * 10 * ROWS;
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int ri = 0; ri < ROWS; ++ri) {
+                            int want = -1;
+                            if (ri < ntok) want = g3[(size_t)tap * lv[l].L + tok0 + ri];
+                            if (want >= 0 && (want - tok0 < 0 || want - tok0 >= ntok)) return l + 1;
+                            if (tb[tap * ROWS + ri] != lds_pool + (want < 0 ? ntok : want - tok0) * SM) return l + 1;
+                        }
+                }
+            }
         }
     }
     return 0;

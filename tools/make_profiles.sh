@@ -92,9 +92,13 @@ timeout 120 tools/ubench/mfma_valu > $O/r${NN}_mfma_valu_ubench.txt 2>&1
 #     the fused attention + proj_out kernel; the -DMTV_DEEP_STAMP build adds the in-kernel phase anatomy
 timeout 300 tools/ubench/deep_bench check > $O/r${NN}_deep_check.txt 2>&1
 timeout 300 tools/ubench/deep_bench attn >> $O/r${NN}_deep_check.txt 2>&1
+timeout 300 tools/ubench/deep_bench block >> $O/r${NN}_deep_check.txt 2>&1
 if [ -x tools/ubench/deep_bench_stamp ]; then DB=tools/ubench/deep_bench_stamp; else DB=tools/ubench/deep_bench; fi
 (for cfg in "40 4 2" "40 8 4" "16 4 2" "16 8 4"; do timeout 120 $DB chain $cfg 2>&1 | grep -v "final act"; done) > $O/r${NN}_deep_chain.txt
 timeout 120 $DB attn time 2>&1 | grep -v "^ATTN" > $O/r${NN}_deep_attn.txt
+# 10a. k_deep_block (csrc/block.hip): the whole attention block in one launch -- 15 shapes against the double-precision CPU block, the
+#      graph-chain timing of the base model's shapes and the in-kernel stamps (stage 1 | hand-off | stage 2 | hand-off | attention | proj)
+timeout 300 $DB block time > $O/r${NN}_deep_block.txt 2>&1
 # 10b. the level-0/1 kernels in chains: k_conv tiles vs k_conv_win tiles (20 dependent 3x3 convs) and vs k_conv_pw tiles (20 qkv-shaped 1x1
 #      launches), with stamps (the r04_conv_win_stamps.txt / r04_conv_pw_stamps.txt of round 4 are these commands run across kernel versions)
 (timeout 120 $DB win 20 32 16 128; timeout 120 $DB win 20 16 8 256) > $O/r${NN}_conv_win_chain.txt 2>&1
