@@ -123,21 +123,20 @@ struct BlkLds {
     int epoch;
     int total;
 };
-__host__ __device__ inline BlkLds blk_lds(int L, int D, int CS, int ncols) {
+__host__ __device__ inline BlkLds blk_lds(int L, int D, int CS, int ncols, int RQ) {
     BlkLds p;
     p.LP = (L + 15) / 16 * 16;
     p.XS = CS + 8;
     p.WS = CS + 4;
     const int NQ = 3 * D;
     p.xs = 0;
-    p.wt = p.xs + p.LP * p.XS;
+    p.wt = p.xs + (p.LP / RQ) * p.XS;
     int s1 = p.wt + NQ * p.WS;
     s1 = (s1 + 3) & ~3;
     p.stat = s1;
     s1 += 3 * BLK_MAX_NG * 2 * 2;
     p.img = 0;
-    const int img_end = p.LP * (NQ + 4);
-    const int st1 = s1 > img_end ? s1 : img_end;        // (the image overwrites slice + weights after the GEMM; statistics are dead by then too)
+    const int st1 = s1;
     const int kcap = p.LP;
     p.ks = 0;
     p.vt = p.ks + kcap * (D + 4);
@@ -167,16 +166,18 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     const int jl = lane & 15, g = lane >> 4;
     const int blk = blk_usgpr((int)blockIdx.x);
     const int CL = a.CL, CS = a.CS, L = a.L, C = a.C, H = a.H;
-    const int j = blk & (CL - 1);                           // K slice / row share / stage-3 item of this workgroup
+    const int j = blk & (CL - 1);                           // workgroup of the cluster: stage 1 (K slice ks, row group rq), stage 2 row share, stage-3 item
+    const int ks = j & (a.KSN - 1), rq = j >> a.ksn_shift;
+    const int RPQ = a.RPQ, row_base = rq * RPQ;             // this workgroup's rows in stage 1
     const int bh = blk >> a.cl_shift;
     const int b = blk_usgpr(bh / H), h = blk_usgpr(bh - (bh / H) * H);
     const int b1 = a.r * a.r, b2 = b1 + a.t * a.r;
-    const BlkLds lp = blk_lds(L, D, CS, a.ncols);
+    const BlkLds lp = blk_lds(L, D, CS, a.ncols, a.RQ);
     const int LP = lp.LP, XS = lp.XS, WS = lp.WS;
     float* const xs = smem + lp.xs;
     float* const wt = smem + lp.wt;
     double* const sdp = reinterpret_cast<double*>(smem + lp.stat);       // [3 planes][BLK_MAX_NG][2]
-    const int cs0 = j * CS;
+    const int cs0 = ks * CS;
     const int qw_shift = a.qw_shift, QW = 1 << qw_shift;                 // quads per row of the slice
     const int qd = tid & (QW - 1), rl = tid >> qw_shift, RP = BLK_NTH >> qw_shift;
     unsigned long long* const cnt = a.cnt + (size_t)bh * 2;
@@ -195,15 +196,15 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     f32x4 xv[8];
     // (UNCONDITIONAL loads into their final registers inside a wave-uniform branch: a per-lane conditional load ends in a register copy
     //  at the join, and a copy of a loaded value waits for every older load -- deep.hip found that three times)
-    if (blk_usgpr(rl) < L) {                               // this wave's first row (rows ascend with the lane): any row to stage?
-        const int row = rl < L ? rl : 0;
+    if (blk_usgpr(rl) < RPQ && row_base + blk_usgpr(rl) < L) {      // this wave's first row (rows ascend with the lane): any row to stage?
+        const int row = (rl < RPQ && row_base + rl < L) ? row_base + rl : 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const f32x4*>(xcol + (size_t)row * a.x.C + (size_t)(k < xks ? k : 0) * a.x.slab_stride);
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) xv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    constexpr int WU = (NQ * 16 + BLK_NTH - 1) / BLK_NTH;                // weight quads per thread at CS = 64
+    constexpr int WU = (NQ * 32 + BLK_NTH - 1) / BLK_NTH;                // weight quads per thread at CS = 128
     f32x4 wreg[WU];
     {
         const float* wb = a.Wq + (size_t)(h * NQ) * C + cs0;
@@ -246,8 +247,9 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     {
         double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         const bool wide = (gs & 3) == 0;                                  // a quad lies inside one group
-        auto consume = [&](int row, const f32x4& x) {
-            *reinterpret_cast<f32x4*>(xs + row * XS + 4 * qd) = x;
+        auto consume = [&](int lrow, const f32x4& x) {            // lrow: row within the row group; token = row_base + lrow
+            *reinterpret_cast<f32x4*>(xs + lrow * XS + 4 * qd) = x;
+            const int row = row_base + lrow;
             if (row >= L) return;
             const int p = row >= b2 ? 2 : (row >= b1 ? 1 : 0);
             if (wide) {
@@ -270,14 +272,14 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
 #pragma unroll
             for (int k = 1; k < 8; ++k)
                 if (k < xks) x += xv[k];                                   // slab order
-            if (rl < LP) consume(rl, rl < L ? x : f32x4{0.f, 0.f, 0.f, 0.f});
+            if (rl < RPQ) consume(rl, row_base + rl < L ? x : f32x4{0.f, 0.f, 0.f, 0.f});
         }
-        for (int row = rl + RP; row < LP; row += RP) {
+        for (int row = rl + RP; row < RPQ; row += RP) {
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (row < L) {
+            if (row_base + row < L) {
                 f32x4 t[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(xcol + (size_t)row * a.x.C + (size_t)(k < xks ? k : 0) * a.x.slab_stride);
+                for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(xcol + (size_t)(row_base + row) * a.x.C + (size_t)(k < xks ? k : 0) * a.x.slab_stride);
                 x = t[0];
 #pragma unroll
                 for (int k = 1; k < 8; ++k)
@@ -306,11 +308,42 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     BLK_STAMP(2);
     __syncthreads();
     const unsigned epoch = *reinterpret_cast<const unsigned*>(smem + lp.epoch);
+    if (a.RQ > 1) {
+        // The statistics above cover this row group's rows only: the RQ row groups of a K slice exchange their partial (sum, sum of squares)
+        // -- 3 planes x <= 32 groups x 2 doubles, one 16-byte {lo, tag, hi, tag} granule pair each -- and every one adds them in row-group
+        // order (all get the same bits).  The wait hides under the weight slice still on its way from HBM.
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.stg, 0, (int)a.stg_bytes, 0x00020000);
+        constexpr int NST = 3 * BLK_MAX_NG * 2;
+        const unsigned sbase = (unsigned)(((size_t)bh * a.KSN + ks) * a.RQ) * NST * 16u;
+        if (tid < NST) {
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, sdp[tid]);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{(unsigned)u, epoch, (unsigned)(u >> 32), epoch}, srs, sbase + (unsigned)(rq * NST + tid) * 16u, 0, BLK_SC);
+            double tot = 0.0;
+            for (int q2 = 0; q2 < a.RQ; ++q2) {
+                double v = sdp[tid];
+                if (q2 != rq) {
+                    u32x4 g4;
+                    int tries = 0;
+                    for (;;) {
+                        g4 = __builtin_amdgcn_raw_buffer_load_b128(srs, sbase + (unsigned)(q2 * NST + tid) * 16u, 0, BLK_SC);
+                        if (g4[1] == epoch && g4[3] == epoch) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++tries > BLK_MAX_RETRY) { __hip_atomic_store(a.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                    }
+                    v = __builtin_bit_cast(double, ((unsigned long long)g4[2] << 32) | g4[0]);
+                }
+                tot += v;                                                  // row-group order
+            }
+            sdp[tid] = tot;
+        }
+        __syncthreads();
+    }
     // normalise in place: y = (x - mean) rstd gamma + beta, statistics per plane or over all planes (whole)
     {
         int cur_p = -1;
         f32x4 A = {0.f, 0.f, 0.f, 0.f}, Bc = A;
-        for (int row = rl; row < L; row += RP) {
+        for (int lrow = rl; lrow < RPQ && row_base + lrow < L; lrow += RP) {
+            const int row = row_base + lrow;
             const int p = row >= b2 ? 2 : (row >= b1 ? 1 : 0);
             if (p != cur_p) {
                 cur_p = p;
@@ -343,7 +376,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
                     Bc[k] = be[k] - sc * mu;
                 }
             }
-            f32x4* cell = reinterpret_cast<f32x4*>(xs + row * XS + 4 * qd);
+            f32x4* cell = reinterpret_cast<f32x4*>(xs + lrow * XS + 4 * qd);
             f32x4 v = *cell;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], A[k], Bc[k]);
@@ -353,7 +386,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     __syncthreads();
     BLK_STAMP(3);
     // partial qkv of this K slice: [LP x NQ] = xs [LP x CS] . wt^T; tiles (row tile, column tile) dealt round-robin to the waves
-    const int nrt = LP >> 4;
+    const int nrt = RPQ >> 4;
     constexpr int NCT = NQ / 16;
     constexpr int MAXT = (8 * NCT + 7) / 8;                              // tiles per wave at 128 tokens
     f32x4 tacc[MAXT];
@@ -376,7 +409,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
         // the partial tiles leave as data-tagged granules straight from the accumulators -- no LDS image, no drain, no flag: stage 2 polls
         // the data.  Layout [cluster][slice][row pair][col][2 rows]: a lane (col jl, group g) holds rows 4 g .. 4 g + 3 of its column = two
         // 16-byte stores, 16 lanes = 256 contiguous bytes
-        const unsigned pslice = (unsigned)(((size_t)bh * CL + j) * (LP >> 1) * NQ * 16);
+        const unsigned pslice = (unsigned)((((size_t)bh * a.KSN + ks) * (LP >> 1) + (row_base >> 1)) * NQ * 16);
 #pragma unroll
         for (int u = 0; u < MAXT; ++u) {
             const int tl = wave + 8 * u;
@@ -395,7 +428,8 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
     // thread -> (row pair, column): one 16-byte load per slice (2 rows of its column), polled until every slice's tag is this launch's
     {
         const int pp = a.rows_per >> 1, pr0 = j * pp;
-        const unsigned pb = (unsigned)((size_t)bh * CL * (LP >> 1) * NQ * 16);
+        const unsigned pb = (unsigned)((size_t)bh * a.KSN * (LP >> 1) * NQ * 16);
+        const int KSN = a.KSN;
         const unsigned gb = (unsigned)((size_t)bh * L * NQ * 8);
         for (int e = tid; e < pp * NQ; e += BLK_NTH) {
             const int prl = e / NQ, col = e - prl * NQ;
@@ -408,7 +442,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b128(prs, o + (unsigned)(k < CL ? k : 0) * sstride, 0, BLK_SC);
+                for (int k = 0; k < 16; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b128(prs, o + (unsigned)(k < KSN ? k : 0) * sstride, 0, BLK_SC);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) ok = ok && t[k][1] == epoch && t[k][3] == epoch;
                 if (ok) break;
@@ -418,7 +452,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
             float v0 = __uint_as_float(t[0][0]), v1 = __uint_as_float(t[0][2]);
 #pragma unroll
             for (int k = 1; k < 16; ++k)
-                if (k < CL) { v0 += __uint_as_float(t[k][0]); v1 += __uint_as_float(t[k][2]); }     // slice order
+                if (k < KSN) { v0 += __uint_as_float(t[k][0]); v1 += __uint_as_float(t[k][2]); }     // slice order
             const float bias = a.bq[h * NQ + col];
             blk_gu64* dst = (blk_gu64*)(unsigned long long)(reinterpret_cast<char*>(a.qkv) + gb + (size_t)((2 * pr) * NQ + col) * 8);
             __hip_atomic_store(dst, ((unsigned long long)epoch << 32) | __float_as_uint(v0 + bias), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -611,56 +645,72 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
 // =====================================================================================
 size_t deep_block_smem_bytes(const DeepBlockArgs& a) {
     const int D = a.C / a.H;
-    return (size_t)blk_lds(a.L, D, a.CS, a.ncols).total * 4;
+    return (size_t)blk_lds(a.L, D, a.CS, a.ncols, a.RQ).total * 4;
 }
 
 // Cluster size / slicing of one attention block.  `a` arrives with B, L, C, H, r, t, whole, gs and the input set; on success CL, CS
 // and the stage-2 / stage-3 work split are filled in.  false: this block keeps the three-launch path of deep.hip.
-bool deep_block_configure(DeepBlockArgs& a, int force_cl) {
+bool deep_block_configure(DeepBlockArgs& a, int force_cl, int force_rq) {
     if (a.B < 1 || a.H < 1 || a.L < 1 || a.L > 128 || a.C % a.H || (a.C & 15)) return false;
     if (a.H > 8 || (a.H & (a.H - 1))) return false;                      // the heads are the output slabs: 1, 2, 4 or 8
     const int d = a.C / a.H;
     if (d != 16 && d != 32 && d != 64) return false;
     if (a.gs < 1 || a.C % a.gs) return false;
     if (!(a.x.ks == 1 || a.x.ks == 2 || a.x.ks == 4 || a.x.ks == 8)) return false;
-    const int nqt = (a.L + 15) / 16;
-    int best = 0;
-    for (int CL = 1; CL <= 16; CL *= 2) {
-        if (force_cl > 0 && CL != force_cl) continue;
-        if (a.C % CL) continue;
-        const int CS = a.C / CL;
-        if (CS < 16 || CS > 64 || (CS & (CS - 1)) || CS % a.gs || CS / a.gs > BLK_MAX_NG) continue;
-        if ((long)a.B * a.H * CL > 128) continue;                          // all workgroups resident together, on half the chip
-        int ncp = CL > nqt ? CL / nqt : 1;                               // column parts: one stage-3 item per workgroup where the cluster allows,
-        while (a.C / ncp > 256) ncp *= 2;                                 // at most 256 columns per item (two column tiles per wave)
-        if (a.C % ncp) continue;
-        const int ncols = a.C / ncp;
-        if (ncols > 256 || (ncols & 15)) continue;
-        DeepBlockArgs probe = a;
-        probe.CS = CS; probe.ncols = ncols;
-        if (deep_block_smem_bytes(probe) > 160 * 1024) continue;
-        best = CL;                                                          // the largest admissible cluster
+    const int LP = (a.L + 15) / 16 * 16, nqt = LP / 16;
+    // Row groups: above 32 tokens a workgroup stages 32-row groups of its K slice instead of all tokens (fewer, wider K slices: the partial
+    // q | k | v rows that cross the cluster shrink with the slice count -- at [128 x 512] 16 slices were 12.6 MB of hand-off traffic per block)
+    int rq_want = force_rq > 0 ? force_rq : (LP <= 32 ? 1 : (LP / 32 >= 4 ? 4 : LP / 32));
+    for (int RQ = rq_want; RQ >= 1; RQ /= 2) {
+        if (LP % (16 * RQ)) continue;
+        int best = 0;
+        for (int CL = RQ; CL <= 16; CL *= 2) {
+            if (force_cl > 0 && CL != force_cl) continue;
+            const int KSN = CL / RQ;
+            if (a.C % KSN) continue;
+            const int CS = a.C / KSN;
+            if (CS < 16 || CS > 128 || (CS & (CS - 1)) || CS % a.gs || CS / a.gs > BLK_MAX_NG) continue;
+            if ((long)a.B * a.H * CL > 128) continue;                          // all workgroups resident together, on half the chip
+            int ncp = CL > nqt ? CL / nqt : 1;                               // column parts: one stage-3 item per workgroup where the cluster allows,
+            while (a.C / ncp > 256) ncp *= 2;                                 // at most 256 columns per item (two column tiles per wave)
+            if (a.C % ncp) continue;
+            const int ncols = a.C / ncp;
+            if (ncols > 256 || (ncols & 15)) continue;
+            DeepBlockArgs probe = a;
+            probe.CS = CS; probe.ncols = ncols; probe.RQ = RQ;
+            if (deep_block_smem_bytes(probe) > 160 * 1024) continue;
+            best = CL;                                                          // the largest admissible cluster
+        }
+        if (!best) continue;
+        a.CL = best;
+        a.RQ = RQ;
+        a.KSN = best / RQ;
+        a.RPQ = LP / RQ;
+        a.CS = a.C / a.KSN;
+        a.nqt = nqt;
+        a.ncp = best > nqt ? best / nqt : 1;
+        while (a.C / a.ncp > 256) a.ncp *= 2;
+        a.ncols = a.C / a.ncp;
+        a.rows_per = 2 * ((LP / 2 + best - 1) / best);                       // row PAIRS are dealt to the workgroups
+        return true;
     }
-    if (!best) return false;
-    a.CL = best;
-    a.CS = a.C / best;
-    a.nqt = nqt;
-    a.ncp = best > nqt ? best / nqt : 1;
-    while (a.C / a.ncp > 256) a.ncp *= 2;
-    a.ncols = a.C / a.ncp;
-    a.rows_per = 2 * (((a.L + 15) / 16 * 8 + best - 1) / best);          // row PAIRS are dealt to the workgroups
-    return true;
+    return false;
 }
 
-size_t deep_block_part_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.CL * ((a.L + 15) / 16 * 16) * 3 * a.C * 2; }   // 8-byte {data, tag} granules, rows padded to 16
+size_t deep_block_part_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.KSN * ((a.L + 15) / 16 * 16) * 3 * a.C * 2; }   // 8-byte {data, tag} granules, rows padded to 16
 size_t deep_block_qkv_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.L * 3 * a.C * 2; }     // 8-byte {data, tag} granules
+size_t deep_block_stg_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.H * a.KSN * a.RQ * (3 * BLK_MAX_NG * 2) * 4; }   // 16-byte granule pairs
 
 hipError_t launch_deep_block(const DeepBlockArgs& a0, hipStream_t s) {
     DeepBlockArgs a = a0;
     const int d = a.C / a.H;
-    if (a.CL < 1 || (a.CL & (a.CL - 1)) || a.CL > 16 || a.CS * a.CL != a.C || a.CS < 16 || a.CS > 64) return hipErrorInvalidValue;
+    if (a.CL < 1 || (a.CL & (a.CL - 1)) || a.CL > 16 || a.RQ < 1 || (a.RQ & (a.RQ - 1)) || a.KSN * a.RQ != a.CL || a.CS * a.KSN != a.C || a.CS < 16 || a.CS > 128)
+        return hipErrorInvalidValue;
+    if (a.RPQ * a.RQ != (a.L + 15) / 16 * 16 || (a.RPQ & 15)) return hipErrorInvalidValue;
     if ((long)a.B * a.H * a.CL > 128 || a.ncols > 256 || (a.ncols & 15) || a.ncols * a.ncp != a.C) return hipErrorInvalidValue;
-    if (!a.part || !a.qkv || !a.cnt || !a.fault || !a.x.p || !a.out) return hipErrorInvalidValue;
+    if (!a.part || !a.qkv || !a.cnt || !a.fault || !a.x.p || !a.out || (a.RQ > 1 && !a.stg)) return hipErrorInvalidValue;
+    a.stg_bytes = (unsigned)(deep_block_stg_floats(a) * 4);
+    a.ksn_shift = __builtin_ctz(a.KSN);
     a.part_bytes = (unsigned)(deep_block_part_floats(a) * 4);
     a.qkv_bytes = (unsigned)(deep_block_qkv_floats(a) * 4);
     a.cl_shift = __builtin_ctz(a.CL);

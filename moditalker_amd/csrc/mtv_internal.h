@@ -373,7 +373,11 @@ struct DeepBlockArgs {
     const float* bp;         // [C]
     float* out;              // slab 0 of [H][clips][L][C]: slab h = head h's share of the projection (+ input slabs h, h + H, ...; bias in slab 0)
     unsigned out_slab_stride;
-    int CL, CS;              // workgroups per cluster = K slices of the qkv GEMM; channels per slice = C / CL
+    int CL, CS;              // workgroups per cluster = KSN x RQ; channels per K slice = C / KSN
+    int KSN, RQ, RPQ;        // K slices of the qkv GEMM x row groups of a cluster (RQ = 1: every workgroup stages all tokens of its slice; RQ > 1: its
+                             // RPQ = padded rows / RQ rows only -- the GroupNorm statistics of the row groups are exchanged in-launch); CL = KSN RQ
+    float* stg;              // RQ > 1: scratch [B H][KSN][RQ][192] 16-byte granule pairs: partial statistics (fp64 lo | hi) of a row group
+    unsigned stg_bytes;
     float* part;             // scratch [B H][CL][L][3d]: partial qkv of the K slices
     float* qkv;              // scratch [B H][L][3d] 8-byte {value, epoch tag} granules: the head's q | k | v rows (bias added)
     unsigned long long* cnt; // [B H][2] monotonic counters (never reset): [0] arrivals of hand-off 1, [1] entry tickets (-> the launch's epoch)
@@ -381,7 +385,7 @@ struct DeepBlockArgs {
     int rows_per;            // stage 2: rows a workgroup reduces = ceil(L / CL)
     int nqt, ncp, ncols;     // stage 3: query tiles, column parts, columns per part (C / ncp <= 256)
     // ---- derived by launch_deep_block
-    int cl_shift, qw_shift;  // log2(CL), log2(CS / 4)
+    int cl_shift, qw_shift, ksn_shift;  // log2(CL), log2(CS / 4), log2(KSN)
     unsigned part_bytes, qkv_bytes;   // sizes of the two scratch buffers (buffer descriptors)
     double inv_n[4];         // 1 / (tokens x gs) of plane 0, 1, 2 and of all planes together
     unsigned long long* dbg; // -DMTV_DEEP_STAMP builds: phase timestamps, else unused
@@ -473,10 +477,11 @@ bool deep_attn_configure(DeepAttnArgs& a);                // fills HPW / NC / gr
 hipError_t launch_deep_attn(const DeepAttnArgs& a, hipStream_t s);
 hipError_t deep_init_attrs();
 // whole attention block of a deep level in one launch (block.hip)
-bool deep_block_configure(DeepBlockArgs& a, int force_cl = 0);   // picks the cluster size (force_cl > 0: that one or nothing); false: keep the three-launch path
+bool deep_block_configure(DeepBlockArgs& a, int force_cl = 0, int force_rq = 0);   // picks the cluster size (force_cl > 0: that one or nothing); false: keep the three-launch path
 size_t deep_block_smem_bytes(const DeepBlockArgs& a);
 size_t deep_block_part_floats(const DeepBlockArgs& a);    // scratch sizes of a configured block
 size_t deep_block_qkv_floats(const DeepBlockArgs& a);
+size_t deep_block_stg_floats(const DeepBlockArgs& a);
 hipError_t launch_deep_block(const DeepBlockArgs& a, hipStream_t s);
 hipError_t deep_block_init_attrs();
 hipError_t launch_linear(const LinearArgs& a, hipStream_t s);

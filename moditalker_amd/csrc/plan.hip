@@ -806,7 +806,8 @@ struct Builder {
             static const int max_l = []() { const char* e = getenv("MTV_BLOCK_MAX_L"); return e ? atoi(e) : 32; }();
             static const long max_lc = []() { const char* e = getenv("MTV_BLOCK_MAX_LC"); return e ? atol(e) : 128L * 256; }();
             const bool pays = L.L <= max_l || (long)L.L * C <= max_lc || deep_opt(MTV_DEEP_OPT_BLOCK_ALL, "MTV_DEEP_BLOCK_ALL", false);
-            if (pays && (deep_block_configure(ba, force_cl) || (force_cl && deep_block_configure(ba, 0)))) {
+            static const int force_rq = []() { const char* e = getenv("MTV_BLOCK_RQ"); return e ? atoi(e) : 0; }();
+            if (pays && (deep_block_configure(ba, force_cl, force_rq) || ((force_cl || force_rq) && deep_block_configure(ba, 0, 0)))) {
                 Tens out;
                 out.lvl = lvl; out.C = C; out.ks = H;
                 out.slab = (unsigned)((size_t)deep_clips() * L.L * C);
@@ -814,16 +815,17 @@ struct Builder {
                 // Scratch and counters belong to THIS op (the same op of the context's other plans -- forward / step parities -- shares them:
                 // launches are serial).  Never shared between ops: a granule is valid when its tag equals the reader's epoch, and two ops
                 // count their epochs separately -- in a shared buffer op B would accept what op A wrote at the same count.
-                const std::string okey = nm + ".B" + std::to_string(B) + ".CL" + std::to_string(ba.CL);
+                const std::string okey = nm + ".B" + std::to_string(B) + ".CL" + std::to_string(ba.CL) + ".K" + std::to_string(ba.KSN);
                 const size_t pf = deep_block_part_floats(ba), qf = deep_block_qkv_floats(ba);
                 ba.part = c->buf("deep.block.part." + okey, pf);
                 ba.qkv = c->buf("deep.block.qkv." + okey, qf);
+                if (ba.RQ > 1) ba.stg = c->buf("deep.block.stg." + okey + ".RQ" + std::to_string(ba.RQ), deep_block_stg_floats(ba));
                 // entry tickets: 64-bit, monotonic (never reset), per (clip, head)
                 ba.cnt = reinterpret_cast<unsigned long long*>(c->buf("deep.block.cnt." + okey, (size_t)B * H * 2 * 2));
                 ba.fault = c->fault_d;
                 ba.out = out.p;
                 ba.out_slab_stride = out.slab;
-                if (!out.p || !ba.part || !ba.qkv || !ba.cnt || !ba.fault) { err = "deep block allocation failed at " + nm; return Tens{}; }
+                if (!out.p || !ba.part || !ba.qkv || !ba.cnt || !ba.fault || (ba.RQ > 1 && !ba.stg)) { err = "deep block allocation failed at " + nm; return Tens{}; }
                 c->taps[nm + ".out"] = {lvl, C};
                 c->bufs["tap." + nm + ".out"] = out.p;
                 c->tap_slabs[nm + ".out"] = {out.ks, out.slab};
@@ -839,7 +841,7 @@ struct Builder {
                     c->work.bytes_weights_other += 4.0 * (4.0 * (double)C * C + 4.0 * C);
                 }
                 char tag[96];
-                snprintf(tag, sizeof tag, "[L%d d%d %s blk cl%d,cs%d]", L.L, d, whole ? "1d" : "2d", ba.CL, ba.CS);
+                snprintf(tag, sizeof tag, "[L%d d%d %s blk cl%d,cs%d,rq%d]", L.L, d, whole ? "1d" : "2d", ba.CL, ba.CS, ba.RQ);
                 auto bop = std::make_shared<DeepBlockArgs>(ba);
                 push("attn:" + nm + tag, [bop](hipStream_t s) { return launch_deep_block(*bop, s); },
                      aflops + 2.0 * B * (double)L.L * C * 4.0 * C, 4.0 * B * L.L * (2.0 * C) + 4.0 * (4.0 * (double)C * C + 4.0 * C));

@@ -483,7 +483,7 @@ static int do_attn(bool timing) {
 // ---------------------------------------------------------------------------------------------------------------- k_deep_block
 // the whole attention block in one launch (block.hip) against a double-precision CPU restatement of
 // GroupNorm -> qkv -> QKVAttentionLegacy -> proj_out + residual; the reduced qkv scratch is checked too (localises a failure)
-static int run_block(int r, int t, int C, int H, int whole, int x_ks, int B, int force_cl, bool timing) {
+static int run_block(int r, int t, int C, int H, int whole, int x_ks, int B, int force_cl, bool timing, int force_rq = 0) {
     const int b1 = r * r, b2 = b1 + t * r, L = b2 + t * r, d = C / H, gs = C / 32 > 0 ? C / 32 : 1;
     std::vector<float> Wq((size_t)3 * C * C), bq(3 * C), Wp((size_t)C * C), bp(C), ga(C), be(C), xr;
     const float wsc = 1.0f / sqrtf((float)C);
@@ -499,7 +499,8 @@ static int run_block(int r, int t, int C, int H, int whole, int x_ks, int B, int
     a.scale = 1.0f / sqrtf(sqrtf((float)d));
     a.gamma = dup(ga); a.beta = dup(be); a.gs = gs;
     a.Wq = dup(Wq); a.bq = dup(bq); a.Wp = dup(Wp); a.bp = dup(bp);
-    if (!deep_block_configure(a, force_cl)) { printf("block L%d C%d d%d cl%d: not configurable\n", L, C, d, force_cl); return force_cl ? 0 : 1; }
+    if (!deep_block_configure(a, force_cl, force_rq)) { printf("block L%d C%d d%d cl%d rq%d: not configurable\n", L, C, d, force_cl, force_rq); return (force_cl || force_rq) ? 0 : 1; }
+    if (a.RQ > 1) a.stg = dnew<float>(deep_block_stg_floats(a));
     const size_t slab = (size_t)B * L * C;
     float* out = dnew<float>((size_t)8 * slab);
     a.out = out; a.out_slab_stride = (unsigned)slab;
@@ -579,8 +580,8 @@ static int run_block(int r, int t, int C, int H, int whole, int x_ks, int B, int
             }
     }
     const bool ok = !nan && !fault && worst <= 1e-4 * std::max(1.0, sc2) && worst_q <= 1e-4 * 8;
-    printf("block L%-3d C%-3d d%-2d H%d %s x_ks%d B%d  cl%d cs%d -> %d WGs, %zu B LDS  qkv max|err| %.3e  out max|err| %.3e (|ref| <= %.2f)%s%s  %s\n", L, C, d, H,
-           whole ? "1d" : "2d", x_ks, B, a.CL, a.CS, B * H * a.CL, deep_block_smem_bytes(a), worst_q, worst, sc2, nan ? " NaN" : "", fault ? " FAULT(hand-off timeout)" : "",
+    printf("block L%-3d C%-3d d%-2d H%d %s x_ks%d B%d  cl%d cs%d rq%d -> %d WGs, %zu B LDS  qkv max|err| %.3e  out max|err| %.3e (|ref| <= %.2f)%s%s  %s\n", L, C, d, H,
+           whole ? "1d" : "2d", x_ks, B, a.CL, a.CS, a.RQ, B * H * a.CL, deep_block_smem_bytes(a), worst_q, worst, sc2, nan ? " NaN" : "", fault ? " FAULT(hand-off timeout)" : "",
            ok ? "PASS" : "FAIL");
     if (timing && ok) {
         hipStream_t s; CK(hipStreamCreate(&s));
@@ -624,9 +625,11 @@ static int do_block(bool timing) {
     bad += run_block(8, 4, 512, 8, 1, 4, 1, 0, timing);       // 128-token blocks (in7 / in8 / out2 .. out4), AttentionBlock1D
     bad += run_block(8, 4, 512, 8, 0, 4, 1, 0, timing);       // ... per plane (64 | 32 | 32)
     bad += run_block(8, 4, 256, 8, 1, 8, 1, 0, timing);       // in6.a1: d = 32
-    if (timing) {                                             // other cluster sizes on the two headline shapes
+    if (timing) {                                             // other cluster shapes on the headline shapes
         bad += run_block(4, 2, 512, 8, 1, 8, 1, 8, true);
-        bad += run_block(8, 4, 512, 8, 1, 4, 1, 8, true);
+        bad += run_block(8, 4, 512, 8, 1, 4, 1, 0, true, 1);     // [128 x 512] with every workgroup staging all tokens (16 slices of 32 channels)
+        bad += run_block(8, 4, 512, 8, 1, 4, 1, 0, true, 2);     // two row groups (8 slices of 64 channels)
+        bad += run_block(8, 4, 512, 8, 0, 4, 1, 0, true, 2);
     }
     bad += run_block(8, 4, 512, 8, 1, 4, 2, 0, false);        // two clips
     bad += run_block(8, 4, 128, 8, 0, 1, 2, 0, false);        // the test-size model: d = 16, groups of 4 channels
