@@ -133,28 +133,37 @@ __device__ __forceinline__ void touch_kernargs() {
     // get interleaved with the first real argument loads and the misses serialise again)
     unsigned t0, t1, t2, t3, t4, t5, t6, t7;
     constexpr int LAST = BYTES - 4;              // (the block need not start on a line boundary)
-    asm volatile(
-        "s_load_dword %0, %8, 0x0\n\t"
-        "s_load_dword %1, %8, %9\n\t"
-        "s_load_dword %2, %8, %10\n\t"
-        "s_load_dword %3, %8, %11\n\t"
-        "s_load_dword %4, %8, %12\n\t"
-        "s_load_dword %5, %8, %13\n\t"
-        "s_load_dword %6, %8, %14\n\t"
-        "s_load_dword %7, %8, %15\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
-        : "s"(ka), "n"(BYTES > 64 ? 64 : LAST), "n"(BYTES > 128 ? 128 : LAST), "n"(BYTES > 192 ? 192 : LAST),
-          "n"(BYTES > 256 ? 256 : LAST), "n"(BYTES > 320 ? 320 : LAST), "n"(BYTES > 384 ? 384 : LAST), "n"(BYTES > 448 ? 448 : LAST)
-        : "memory");
-    if constexpr (BYTES > 512) {                 // (round 5: DeepArgs outgrew eight lines)
+    if constexpr (BYTES <= 512) {
+        asm volatile(
+            "s_load_dword %0, %8, 0x0\n\t"
+            "s_load_dword %1, %8, %9\n\t"
+            "s_load_dword %2, %8, %10\n\t"
+            "s_load_dword %3, %8, %11\n\t"
+            "s_load_dword %4, %8, %12\n\t"
+            "s_load_dword %5, %8, %13\n\t"
+            "s_load_dword %6, %8, %14\n\t"
+            "s_load_dword %7, %8, %15\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+            : "s"(ka), "n"(BYTES > 64 ? 64 : LAST), "n"(BYTES > 128 ? 128 : LAST), "n"(BYTES > 192 ? 192 : LAST),
+              "n"(BYTES > 256 ? 256 : LAST), "n"(BYTES > 320 ? 320 : LAST), "n"(BYTES > 384 ? 384 : LAST), "n"(LAST)
+            : "memory");
+    } else {                                     // (round 5: DeepArgs outgrew eight lines -- ten loads, still ONE wait)
         unsigned t8, t9;
         asm volatile(
-            "s_load_dword %0, %2, %3\n\t"
-            "s_load_dword %1, %2, %4\n\t"
+            "s_load_dword %0, %10, 0x0\n\t"
+            "s_load_dword %1, %10, 0x40\n\t"
+            "s_load_dword %2, %10, 0x80\n\t"
+            "s_load_dword %3, %10, 0xc0\n\t"
+            "s_load_dword %4, %10, 0x100\n\t"
+            "s_load_dword %5, %10, 0x140\n\t"
+            "s_load_dword %6, %10, 0x180\n\t"
+            "s_load_dword %7, %10, 0x1c0\n\t"
+            "s_load_dword %8, %10, 0x200\n\t"
+            "s_load_dword %9, %10, %11\n\t"
             "s_waitcnt lgkmcnt(0)"
-            : "=&s"(t8), "=&s"(t9)
-            : "s"(ka), "n"(512), "n"(BYTES > 576 ? 576 : LAST)
+            : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9)
+            : "s"(ka), "n"(BYTES > 576 ? 576 : LAST)
             : "memory");
     }
     __builtin_amdgcn_sched_barrier(0);           // nothing (in particular no argument load) is scheduled above this
