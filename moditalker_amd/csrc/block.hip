@@ -12,7 +12,7 @@
 //            stages ALL tokens of its channel slice (adding the input's K-slice slabs in slab order, as every consumer of the
 //            deep levels does), computes the GroupNorm statistics of its groups itself (per plane, or over all planes for
 //            AttentionBlock1D), normalises once, multiplies by W_qkv[head's 3d rows][slice] -> partial [L x 3d]   -> scratch
-//   hand-off 1 (cluster-wide arrival counter)
+//   hand-off 1 (data-tagged granules, see below)
 //   stage 2  workgroup j adds the CL partials of ITS rows (slice order: run-to-run bit-equal) + bias -> the head's q | k | v rows
 //   hand-off 2
 //   stage 3  workgroup j = (query tile, column part): K rows, V^T and its 16 queries to LDS, S^T = K Q^T per key tile (a query is
@@ -21,13 +21,15 @@
 //            partial result goes to output slab `head` (slab h also carries input slab h as the residual, slab 0 the bias).
 // The output is a deep tensor of H slabs: its consumers add them up (deep.hip).
 //
-// Hand-offs inside the launch follow cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "valid forms": payload by
-// 8-byte agent-scope (sc1, write-through) atomic stores, every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier,
-// ONE lane takes the cluster's ticket (relaxed agent atomic add on a 64-bit monotonic counter: no reset, no ABA), polls it with
-// relaxed agent loads + s_sleep, workgroup barrier, payload read back with 8-byte agent-scope atomic loads (L1-bypassing) --
-// correct under any workgroup -> XCD placement.  All workgroups of the launch must be resident together: the grid is B x H x CL
-// <= 128 workgroups of 512 threads (one per CU on half the chip).  A wait that exceeds ~20 ms raises *fault and falls through
-// (garbage, never a hang); the host checks the flag (mtv_last_error: "in-launch hand-off timed out").
+// Hand-offs inside the launch (MI355X_MICROARCH.md, hand-off price list: "8-byte {data, tag} granules", no drain, no flag, no ordering): every
+// workgroup takes ONE entry ticket on its cluster's 64-bit monotonic counter at kernel entry (relaxed agent atomic add; never reset: no ABA) -- ticket n
+// belongs to launch n / CL, the EPOCH, which tags every granule the launch writes; its round trip hides under the first loads.  Writers use 16-byte
+// sc0 sc1 (write-through) stores of two {value, epoch} granules and never wait; readers poll the data itself with sc0 sc1 (L1-bypassing) loads until
+// every tag is the epoch.  Correct under any workgroup -> XCD placement.  Scratch and counters belong to ONE op (two ops count their epochs
+// separately: in a shared buffer op B would accept what op A wrote at the same count).  All workgroups of the launch must be resident together
+// (a poll waits for workgroups of the same launch): the grid is B x H x CL <= 128 workgroups of 512 threads, one per CU on half the chip.
+// A poll that exceeds 2^18 retries raises *fault (host-mapped) and falls through -- garbage, never a hang; the host refuses every later call on
+// the context (plan.hip check_ready, mtv_last_error: "an in-launch hand-off ... timed out").
 #include <cstdio>
 #include <cstdlib>
 
@@ -41,7 +43,6 @@ namespace {
 
 constexpr int BLK_NTH = 512;
 constexpr int BLK_MAX_NG = 32;        // GroupNorm groups per channel slice
-constexpr unsigned long long BLK_WAIT_TICKS = 60000000ull;    // s_memtime ticks (shader clock, ~2.1 GHz here): ~30 ms
 constexpr int BLK_MAX_RETRY = 1 << 18;                        // granule polls per thread (x s_sleep 1: a few ms)
 constexpr int BLK_SC = 17;                                    // buffer cache policy sc0 | sc1: write-through stores, L1 / L2-bypassing loads
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -49,18 +50,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long blk_gu64;
 
 __device__ __forceinline__ int blk_usgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ void blk_park_quad(float* dst, const f32x4& v) {          // write-through (sc1) 8-byte stores
-    blk_gu64* d = (blk_gu64*)(unsigned long long)dst;
-    __hip_atomic_store(d, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(d + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ f32x4 blk_fetch_quad(const float* src) {                   // L1-bypassing (sc1) 8-byte loads
-    const blk_gu64* s = (const blk_gu64*)(unsigned long long)src;
-    const unsigned long long t0 = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t1 = __hip_atomic_load(s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return f32x4{__uint_as_float((unsigned)t0), __uint_as_float((unsigned)(t0 >> 32)), __uint_as_float((unsigned)t1), __uint_as_float((unsigned)(t1 >> 32))};
-}
 
 // ---- data-tagged granules (MI355X_MICROARCH.md, hand-off price list: 8-byte {data, tag}, no drain, no flag): a float travels with
 // the launch's epoch; the reader re-reads a granule until its tag is this launch's.  Two granules per 16-byte store / load.
@@ -73,26 +62,6 @@ __device__ __forceinline__ bool blk_get_granules(__amdgpu_buffer_rsrc_t rs, unsi
     const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 16, 0, BLK_SC);
     *out = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(b[0]), __uint_as_float(b[2])};
     return a[1] == tag && a[3] == tag && b[1] == tag && b[3] == tag;
-}
-
-// Cluster-wide hand-off: every workgroup of the cluster has parked its payload (all threads call this).  The counter only ever
-// grows: arrival n belongs to round n / CL, the round is complete when the counter reaches (n / CL + 1) CL.
-__device__ __forceinline__ void blk_handoff(unsigned long long* cnt, int cl_shift, int* fault, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its write-through stores
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long target = ((old >> cl_shift) + 1ull) << cl_shift;
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memtime() - t0 > BLK_WAIT_TICKS) {
-                __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (host-mapped word: a plain store, no PCIe atomic)
-                break;
-            }
-        }
-    }
-    __syncthreads();
 }
 
 __device__ __forceinline__ float blk_swap_max16(float x) {
@@ -117,7 +86,7 @@ __device__ __forceinline__ float blk_swap_max32(float x) {
 struct BlkLds {
     int LP;                 // token rows padded to a multiple of 16
     int XS, WS;             // row strides of the staged input slice / qkv weight slice
-    int xs, wt, stat, img;  // stage 1: input slice [LP][XS] | weights [3D][WS] | statistics (doubles) | result image [LP][3D + 4] (aliases xs / wt)
+    int xs, wt, stat, img;  // stage 1: input slice [rows of a row group][XS] | weights [3D][WS] | statistics (doubles)  (img: unused since the partials leave from registers)
     int ks, vt, qs, att, os, ml, po;   // stage 3: K rows [kcap][D + 4] | V^T [D][kcap + 4] | Q [16][D + 4] | attention rows [16][D + 8] |
                                        // key-tile partials [8][16][D + 4] | (m, l) [8][16][2] | proj image [16][ncols + 4]
     int epoch;
