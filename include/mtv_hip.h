@@ -216,6 +216,12 @@ int mtv_selftest_geometry(int res, int frames, int n_levels);
  * im2col tables (unet.py:178-207 ResBlock convs incl. the Upsample of :531-598).  0 = all agree, else 1 + the first level that
  * does not (<0: bad arguments). */
 int mtv_selftest_deep(int res, int frames, int n_levels);
+/* Host-only self-test of k_deep_block's work split (csrc/block.hip: one attention block of a deep level -- unet.py:210-300, 303-326 -- in one
+ * launch): for a level of `tokens` tokens (<= 128), `channels`, `heads`, `batch` clips it configures the cluster (K slices x row groups), and checks
+ * that the grid stays within the residency bound, LDS within 160 KB, that stage 2 deals every row pair to exactly one workgroup and stage 3 every
+ * (query tile, column part) to exactly one, and that every granule offset of the three scratch buffers lies inside its allocation.
+ * Returns 0 when all hold, 1 when the shape is (legitimately) not configurable, > 1 on a violated invariant, < 0 on bad arguments. */
+int mtv_selftest_block(int tokens, int channels, int heads, int batch);
 /* Host-only self-test of k_conv_win's window arithmetic (csrc/deep.hip: the contiguous range of source tokens a row tile of a 3x3
  * conv stages in LDS): for row tiles of 16 and 32 tokens at every level, same-level and nearest-upsampled source, the window lies inside
  * the source tensor and contains the source token of every tap of every output row (the taps of mtv_debug_gather_index).  0 = ok,

@@ -118,6 +118,7 @@ SYMBOLS = [
     ("mtv_xattn_forward", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     ("mtv_selftest_geometry", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_selftest_deep", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("mtv_selftest_block", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("mtv_selftest_win", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_gather_index", C.c_int, [C.c_int] * 6),
 ]

@@ -2166,6 +2166,45 @@ int mtv_selftest_deep(int res, int frames, int n_levels) {
     return 0;
 }
 
+int mtv_selftest_block(int tokens, int channels, int heads, int batch) {
+    if (tokens <= 0 || channels <= 0 || heads <= 0 || batch <= 0 || channels % 32) return fail(MTV_ERR_INVALID, "selftest_block: bad arguments");
+    for (int ks : {1, 2, 4, 8}) {
+        DeepBlockArgs a{};
+        a.B = batch; a.L = tokens; a.C = channels; a.H = heads; a.gs = channels / 32; a.x.ks = ks; a.r = 1; a.t = 1;
+        if (!deep_block_configure(a, 0, 0)) return 1;
+        const int d = channels / heads, NQ = 3 * d, LP = (tokens + 15) / 16 * 16;
+        if (a.KSN * a.RQ != a.CL || a.CS * a.KSN != channels || a.CS % a.gs || a.RPQ * a.RQ != LP || (a.RPQ & 15)) return 2;
+        if ((long)batch * heads * a.CL > 128 || deep_block_smem_bytes(a) > 160 * 1024) return 3;
+        if (a.ncols * a.ncp != channels || a.ncols > 256 || (a.ncols & 15) || a.nqt * 16 != LP) return 4;
+        // stage 2: every row pair below L dealt to exactly one workgroup
+        std::vector<int> seen(LP / 2, 0);
+        const int pp = a.rows_per / 2;
+        for (int j = 0; j < a.CL; ++j)
+            for (int prl = 0; prl < pp; ++prl) {
+                const int pr = j * pp + prl;
+                if (2 * pr >= tokens) continue;
+                if (pr >= LP / 2) return 5;
+                ++seen[pr];
+            }
+        for (int pr = 0; 2 * pr < tokens; ++pr)
+            if (seen[pr] != 1) return 5;
+        // stage 3: every (query tile, column part) exactly once
+        std::vector<int> item(a.nqt * a.ncp, 0);
+        for (int j = 0; j < a.CL; ++j)
+            for (int it = j; it < a.nqt * a.ncp; it += a.CL) ++item[(it % a.nqt) * a.ncp + it / a.nqt];
+        for (int v : item)
+            if (v != 1) return 6;
+        // scratch: the largest offset each stage forms lies inside the allocation (bytes)
+        const size_t part_b = deep_block_part_floats(a) * 4, qkv_b = deep_block_qkv_floats(a) * 4, stg_b = deep_block_stg_floats(a) * 4;
+        const size_t bh = (size_t)batch * heads - 1;
+        const size_t pmax = (((bh * a.KSN + (a.KSN - 1)) * (LP / 2) + (LP / 2 - 1)) * NQ + (NQ - 1)) * 16 + 16;
+        const size_t qmax = ((bh * tokens + (tokens - 1)) * NQ + (NQ - 1)) * 8 + 8;
+        const size_t smax = (((bh * a.KSN + (a.KSN - 1)) * a.RQ + (a.RQ - 1)) * 192 + 191) * 16 + 16;
+        if (pmax > part_b || qmax > qkv_b || (a.RQ > 1 && smax > stg_b) || part_b >= 0x7FFFFFFFull || qkv_b >= 0x7FFFFFFFull) return 7;
+    }
+    return 0;
+}
+
 int mtv_debug_gather_index(int res, int frames, int tok, int ky, int kx, int up) {
     if (res <= 0 || frames <= 0 || tok < 0 || tok >= res * res + 2 * frames * res || ky < 0 || ky > 2 || kx < 0 || kx > 2)
         return fail(MTV_ERR_INVALID, "debug_gather_index: bad arguments") - 1;   // (-2: distinct from "padding")

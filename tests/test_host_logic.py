@@ -252,6 +252,20 @@ def test_deep_level_row_tables_match_im2col_tables(R, T, levels):
     assert lib.mtv_selftest_deep(0, 4, 2) < 0            # bad arguments are an error, not a pass
 
 
+@pytest.mark.parametrize("tokens,channels,heads,batch", [(32, 512, 8, 1), (32, 512, 8, 2), (128, 512, 8, 1), (128, 512, 8, 2), (128, 256, 8, 1),
+                                                         (128, 128, 8, 2), (72, 256, 8, 1), (60, 128, 8, 2), (15, 128, 2, 1), (128, 64, 2, 1),
+                                                         (32, 32, 2, 2), (96, 512, 8, 1), (18, 512, 8, 1)])
+def test_one_launch_attention_block_work_split(tokens, channels, heads, batch):
+    """csrc/block.hip, k_deep_block (an attention block of a deep level in one launch): the cluster configuration for the base model's shapes,
+    the test models' and ragged token counts -- grid within the residency bound, LDS within 160 KB, every row pair of stage 2 and every
+    (query tile, column part) of stage 3 dealt to exactly one workgroup, every granule offset inside its scratch buffer (host only)."""
+    from moditalker_amd import _lib
+    lib = _lib.load()
+    assert lib.mtv_selftest_block(tokens, channels, heads, batch) == 0
+    assert lib.mtv_selftest_block(0, 512, 8, 1) < 0
+    assert lib.mtv_selftest_block(32, 512, 16, 1) == 1          # 16 heads: more output slabs than a deep tensor holds -- falls back, legitimately
+
+
 @pytest.mark.parametrize("R,T,levels", [(32, 16, 4), (64, 16, 4), (8, 4, 3), (16, 8, 4), (24, 8, 3), (16, 8, 2), (48, 12, 3)])
 def test_window_staged_conv_window_covers_every_tap(R, T, levels):
     """csrc/deep.hip, k_conv_win: the contiguous source-token window a row tile stages in LDS (conv_win_window, shared by the host's
