@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates every file under profiles/ for round NN on a box with one MI355X (run from the repo root, e.g.
-#   gpurun --timeout 900 -- 'bash tools/make_profiles.sh 01').
+#   gpurun --timeout 1500 -- "MTV_COMMIT=$(git rev-parse --short HEAD) bash tools/make_profiles.sh 05";  there is no .git on the GPU box: pass the commit in).
 # Outputs go to gpurun_out/final/; copy them into profiles/ as the README there names them.
 set -x
 NN=${1:-01}
@@ -47,7 +47,7 @@ pmc_pass SQ SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_V
 echo "pmc passes: $(tr '\n' ' ' < $O/pmc_modes.txt)"
 PS=$(find $O/pmc_SQ -name '*counter_collection.csv' | head -1)
 python tools/pmc_util.py $PS --launches $NL --fetch $PF --write $PW --trace $KT --json $O/pmc_util.json > $O/r${NN}_pmc_util.txt 2>&1
-python tools/update_pmc_traffic.py $O/pmc_util.json "round $NN (tools/make_profiles.sh)" "$(git rev-parse --short HEAD 2>/dev/null)"; cp profiles/pmc_traffic.json $O/pmc_traffic.json
+python tools/update_pmc_traffic.py $O/pmc_util.json "round $NN (tools/make_profiles.sh)" "${MTV_COMMIT:-$(git rev-parse --short HEAD 2>/dev/null)}"; cp profiles/pmc_traffic.json $O/pmc_traffic.json
 # 3. the bench line (N=1, with cpu_baseline and batched_info), quoting the counters just collected
 timeout 500 python bench.py --steps 250 --warmup 25 > $O/r${NN}_bench_n1.json 2>$O/bench.err
 rm -rf $O/pmc_SQ
@@ -65,7 +65,7 @@ if [ -z "$MTV_PROFILES_SKIP_R64_PMC" ]; then
     python tools/pmc_util.py "$(find $O/pmc_SQ_r64 -name '*counter_collection.csv' | head -1)" --launches $NL6 \
         --fetch "$(find $O/pmc_FETCH_SIZE_r64 -name '*counter_collection.csv' | head -1)" --write "$(find $O/pmc_WRITE_SIZE_r64 -name '*counter_collection.csv' | head -1)" \
         --trace $KT6 --json $O/pmc_util_r64.json > $O/r${NN}_pmc_util_res64.txt 2>&1
-    python tools/update_pmc_traffic.py $O/pmc_util_r64.json "round $NN (tools/make_profiles.sh)" "$(git rev-parse --short HEAD 2>/dev/null)" R64; cp profiles/pmc_traffic.json $O/pmc_traffic.json
+    python tools/update_pmc_traffic.py $O/pmc_util_r64.json "round $NN (tools/make_profiles.sh)" "${MTV_COMMIT:-$(git rev-parse --short HEAD 2>/dev/null)}" R64; cp profiles/pmc_traffic.json $O/pmc_traffic.json
     rm -rf $O/kt64 $O/pmc_SQ_r64 $O/pmc_FETCH_SIZE_r64 $O/pmc_WRITE_SIZE_r64
     BARGS=""
 fi
