@@ -1908,8 +1908,31 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
     if ((rc = stage_inputs(c, x_io, cond, image_cond, image_cond_len, batch, s)) != MTV_OK) return rc;
     if ((rc = sampler_setup(c, batch, noise, steps, n_steps, s)) != MTV_OK) return rc;
     // the loop: ONE graph replay per step (even / odd steps alternate between the two statistics arenas); the
-    // step index, its coefficients, its FiLM row and its noise slab are all resolved on the device
-    for (int i = 0; i < n_steps; ++i) {
+    // step index, its coefficients, its FiLM row and its noise slab are all resolved on the device -- so M consecutive steps can just as
+    // well be ONE graph (round 5: M = 8 by default, MTV_STEPS_PER_GRAPH; the hand-over between two graph launches is a few microseconds of
+    // idle GPU per launch: profiles/r05_steps_per_graph_ab.txt)
+    static const int M = []() { const char* e = getenv("MTV_STEPS_PER_GRAPH"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 32 ? 32 : v & ~1 ? v & ~1 : 1); }();
+    int i0 = 0;
+    if (!c->eager && M >= 2) {
+        hipGraphExec_t& gm = c->multi[{batch, M}];
+        while (n_steps - i0 >= M) {
+            if (!gm) {
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+                int rcc = MTV_OK;
+                for (int k = 0; k < M && rcc == MTV_OK; ++k) rcc = run_ops(c, p[k & 1], c->cap_stream);
+                const hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+                if (rcc != MTV_OK) { if (g) (void)hipGraphDestroy(g); return rcc; }
+                if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+                const hipError_t e2 = hipGraphInstantiate(&gm, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e2 != hipSuccess) { gm = nullptr; return fail(MTV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+            }
+            HIPCHK(hipGraphLaunch(gm, s));
+            i0 += M;                                   // (M is even: the next step is an even one again)
+        }
+    }
+    for (int i = i0; i < n_steps; ++i) {
         Plan* q = p[i & 1];
         if (c->eager) {
             if ((rc = run_ops(c, q, s)) != MTV_OK) return rc;

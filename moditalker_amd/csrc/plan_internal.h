@@ -172,6 +172,7 @@ struct mtv_ctx {
     size_t pin_bytes = 0;
     unsigned pin_turn = 0;
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;   // (batch, mode)
+    std::map<std::pair<int, int>, hipGraphExec_t> multi;         // (batch, M): M consecutive sampler steps (even, odd, even, ...) captured as ONE graph
     hipStream_t cap_stream = nullptr;
     bool eager = false;
     mtv_work work{};
@@ -281,6 +282,9 @@ struct mtv_ctx {
         for (auto& kv : plans)
             if (kv.second->g_forward) (void)hipGraphExecDestroy(kv.second->g_forward);
         plans.clear();
+        for (auto& kv : multi)
+            if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        multi.clear();
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (void* p : allocs) (void)hipFree(p);
         if (staging) (void)hipFree(staging);
