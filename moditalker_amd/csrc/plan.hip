@@ -1913,9 +1913,12 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
     // idle GPU per launch: profiles/r05_steps_per_graph_ab.txt)
     static const int M = []() { const char* e = getenv("MTV_STEPS_PER_GRAPH"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 32 ? 32 : v & ~1 ? v & ~1 : 1); }();
     int i0 = 0;
-    if (!c->eager && M >= 2) {
-        hipGraphExec_t& gm = c->multi[{batch, M}];
-        while (n_steps - i0 >= M) {
+    if (!c->eager) {
+        // every graph this context can need is captured by its FIRST call (the tail of a later call must never pay a capture)
+        for (int par = 0; par < 2; ++par)
+            if (!p[par]->g_forward && (rc = capture(c, p[par], &p[par]->g_forward)) != MTV_OK) return rc;
+        if (M >= 2) {
+            hipGraphExec_t& gm = c->multi[{batch, M}];
             if (!gm) {
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -1928,8 +1931,7 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
                 (void)hipGraphDestroy(g);
                 if (e2 != hipSuccess) { gm = nullptr; return fail(MTV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
             }
-            HIPCHK(hipGraphLaunch(gm, s));
-            i0 += M;                                   // (M is even: the next step is an even one again)
+            for (; n_steps - i0 >= M; i0 += M) HIPCHK(hipGraphLaunch(gm, s));     // (M is even: the next step is an even one again)
         }
     }
     for (int i = i0; i < n_steps; ++i) {
