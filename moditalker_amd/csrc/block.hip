@@ -28,7 +28,7 @@
 // every tag is the epoch.  Correct under any workgroup -> XCD placement.  Scratch and counters belong to ONE op (two ops count their epochs
 // separately: in a shared buffer op B would accept what op A wrote at the same count).  All workgroups of the launch must be resident together
 // (a poll waits for workgroups of the same launch): the grid is B x H x CL <= 128 workgroups of 512 threads, one per CU on half the chip.
-// A poll that exceeds 2^18 retries raises *fault (host-mapped) and falls through -- garbage, never a hang; the host refuses every later call on
+// A poll that exceeds 2^21 retries (seconds) raises *fault (host-mapped) and falls through -- garbage, never a hang; the host refuses every later call on
 // the context (plan.hip check_ready, mtv_last_error: "an in-launch hand-off ... timed out").
 #include <cstdio>
 #include <cstdlib>
@@ -43,7 +43,7 @@ namespace {
 
 constexpr int BLK_NTH = 512;
 constexpr int BLK_MAX_NG = 32;        // GroupNorm groups per channel slice
-constexpr int BLK_MAX_RETRY = 1 << 18;                        // granule polls per thread (x s_sleep 1: a few ms)
+constexpr int BLK_MAX_RETRY = 1 << 21;                        // granule polls per thread (x s_sleep 1 + a fabric round trip: seconds -- a bound against a hang, never a pace)
 constexpr int BLK_SC = 17;                                    // buffer cache policy sc0 | sc1: write-through stores, L1 / L2-bypassing loads
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 

@@ -236,7 +236,7 @@ constexpr int DEEP_FIN_FLOATS = 4 + 2 * 96 * 2 * 2;      // flag + [2 consumers]
 // cache policy sc0 | sc1 (write-through, L1-bypassing).  No drain, no flag, no ticket wait: the reader polls the data.
 typedef unsigned deep_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int DEEP_SC = 17;
-constexpr int DEEP_MAX_RETRY = 1 << 18;
+constexpr int DEEP_MAX_RETRY = 1 << 21;      // (seconds: a bound against a hang, never a pace)
 __device__ __forceinline__ void deep_put_granules(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, const f32x4& v, unsigned tag) {
     __builtin_amdgcn_raw_buffer_store_b128(deep_u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag}, rs, byte_off, 0, DEEP_SC);
     __builtin_amdgcn_raw_buffer_store_b128(deep_u32x4{__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag}, rs, byte_off + 16, 0, DEEP_SC);
