@@ -67,7 +67,7 @@ if ss:
     print("```\n")
 pu = rd(f"r{nn}_pmc_util.txt")
 if pu:
-    print("## Counter-derived utilisation (tools/pmc_util.py; PMC passes: " + " ".join(rd("pmc_modes.txt").split()) + ")\n\n```")
+    print("## Counter-derived utilisation (tools/pmc_util.py; PMC passes: " + " ".join((rd("pmc_modes.txt") or rd(f"r{nn}_pmc_modes.txt") or "").split()) + ")\n\n```")
     print(pu.strip())
     print("```\n")
 dc = rd(f"r{nn}_deep_chain.txt")
@@ -81,4 +81,20 @@ for name, title in ((f"r{nn}_conv_win_chain.txt", "k_conv tiles vs k_conv_win ti
     if t:
         print(f"\n## {title}\n\n```")
         print("\n".join(l for l in t.splitlines() if not l.lstrip().startswith("stamps") and not l.startswith("+ ")))
+        print("```")
+
+db = rd(f"r{nn}_deep_block.txt")
+if db:
+    print("\n## k_deep_block: a deep-level attention block in one launch (deep_bench block time: vs the double-precision CPU block; graph chain of 20 launches; stamps = shader-clock ticks since entry)\n\n```")
+    print("\n".join(l for l in db.splitlines() if l.startswith("block") or "us per launch" in l or "stamps wg 0" in l or "CHECK" in l or "differ" in l))
+    print("```")
+for name, title in ((f"r{nn}_deep_block_ab.txt", "same-box A/B: three launches per deep attention block vs k_deep_block where the rule selects it"),
+                    (f"r{nn}_deep_block_all_ab.txt", "same-box A/B: the rule vs k_deep_block on every deep attention block"),
+                    (f"r{nn}_tagged_fin_ab.txt", "same-box A/B: k_deep_finalize passes vs completion inside the producing launch (tagged granules)"),
+                    (f"r{nn}_pool_fold_ab.txt", "same-box A/B: k_pool_down launches vs AvgPool2d inside k_deep_conv"),
+                    (f"r{nn}_steps_per_graph_ab.txt", "sampler steps per hipGraph")):
+    t = rd(name)
+    if t:
+        print(f"\n## {title}\n\n```")
+        print(t.strip())
         print("```")
