@@ -107,6 +107,26 @@ int mtv_ddim_sample(mtv_ctx* ctx, float* x_io, const float* cond, const float* i
                     int image_cond_len, const float* noise, int n_noise,
                     const mtv_ddim_step* steps, int n_steps, int batch, void* stream);
 
+/* Fault state of the in-launch hand-offs.  Some launches of a step exchange data between their own workgroups (k_deep_block's clusters, the
+ * tagged completion of a deep tensor: csrc/block.hip, csrc/deep.hip); a poll that is not served within 2^21 retries (seconds) raises a
+ * host-visible fault word and falls through -- never a hang, but the call's output is then garbage.  The reference raises Python exceptions
+ * synchronously (unet.py:995-1117 is plain torch); here launches are asynchronous, so:
+ *   - mtv_check_fault(ctx) reads the word: MTV_OK, or MTV_ERR_STATE with the explanation in mtv_last_error().  It is meaningful for a call
+ *     once the stream that call ran on has drained -- call it after the synchronisation point you have anyway (it does not synchronise);
+ *   - every later entry point of a faulted context refuses to run (MTV_ERR_STATE): a fault is sticky, destroy the context.
+ * moditalker_amd.DDPM.sample(..., strict=True) / UNetModel.forward(..., strict=True) synchronise the stream and check before returning. */
+int mtv_check_fault(mtv_ctx* ctx);
+/* CUs this context counts on being resident together (the device's multiProcessorCount unless overridden): every grid whose workgroups wait
+ * for each other is planned within it (k_deep_block: half of it; tagged completion: all of it), larger ones fall back to the forms without
+ * in-launch hand-offs (three-launch attention block, k_deep_finalize pass).  A stream whose CU mask (hipExtStreamCreateWithCUMask) leaves
+ * fewer CUs is refused by mtv_forward / mtv_ddim_sample with MTV_ERR_STATE. */
+int mtv_resident_cus(const mtv_ctx* ctx);
+/* Testing aids: contexts created after mtv_debug_resident_cus(n) plan for n co-resident CUs (0 = the device's count / MTV_RESIDENT_CUS);
+ * mtv_debug_arm_fault makes the NEXT mtv_forward / mtv_ddim_sample on this context end with a launch that raises the fault word exactly as a
+ * timed-out poll does (the caller-side path -- same-call detection with strict=True, stickiness -- is then testable without a real time-out). */
+int mtv_debug_resident_cus(int n);
+int mtv_debug_arm_fault(mtv_ctx* ctx);
+
 /* Test/debug: copy an internal activation (token-major [B, L_level, C]) to `dst` (device or host).
  * Names: "in<i>", "mid", "out<i>" = result after the cross-plane attention of that stage. */
 int mtv_debug_tap(mtv_ctx* ctx, const char* name, float* dst, int64_t dst_cap_floats, int* tokens_out, int* channels_out);
@@ -159,11 +179,6 @@ int mtv_debug_force_win(int mt, int nt);
  * unet.py:234,253) on k_conv_pw<mt, ntw> (16 mt rows normalised once into LDS, 8 waves side by side along 128 ntw output channels, ntw = 1 | 2,
  * whole K per wave; csrc/deep.hip) instead of the tuned choice; mt = 0 switches it off again. */
 int mtv_debug_force_pw(int mt, int ntw);
-/* Which attention core the UNet's self-attention launches take (head dim 16 / 32 / 64; process-wide, takes effect at the
- * next launch / graph capture): 0 = the exact-f32 core k_attention everywhere (the default: it is the faster one on
- * MI355X at every shape measured), 1 = the split-bf16 core k_attention_b3 (csrc/attn_b3.hip) on every eligible launch,
- * -1 = k_attention_b3 for segments of >= 256 keys.  The parity tests run both. */
-int mtv_debug_attention_b3(int mode);
 /* Testing aid: attention launches issued (or captured) after this call compute QK^T on the bf16 matrix pipe through a three-term
  * split of q and k at f32 accuracy (k_attention<..., QB = 1>: the 8-wave shapes of d = 16 / 32 / 64; PV stays on the f32
  * instruction): 1 on, 0 off, -1 back to the build default / MTV_ATT_QB. */

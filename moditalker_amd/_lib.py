@@ -103,7 +103,6 @@ SYMBOLS = [
     ("mtv_debug_force_win", C.c_int, [C.c_int, C.c_int]),
     ("mtv_debug_force_pw", C.c_int, [C.c_int, C.c_int]),
     ("mtv_debug_force_b3", C.c_int, [C.c_int, C.c_int, C.c_int]),
-    ("mtv_debug_attention_b3", C.c_int, [C.c_int]),
     ("mtv_debug_attention_qb", C.c_int, [C.c_int]),
     ("mtv_debug_deep", C.c_int, [C.c_int]),
     ("mtv_debug_deep_options", C.c_int, [C.c_int]),
@@ -121,6 +120,10 @@ SYMBOLS = [
     ("mtv_selftest_block", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("mtv_selftest_win", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_gather_index", C.c_int, [C.c_int] * 6),
+    ("mtv_check_fault", C.c_int, [_P]),
+    ("mtv_resident_cus", C.c_int, [_P]),
+    ("mtv_debug_resident_cus", C.c_int, [C.c_int]),
+    ("mtv_debug_arm_fault", C.c_int, [_P]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -619,7 +619,8 @@ size_t deep_block_smem_bytes(const DeepBlockArgs& a) {
 
 // Cluster size / slicing of one attention block.  `a` arrives with B, L, C, H, r, t, whole, gs and the input set; on success CL, CS
 // and the stage-2 / stage-3 work split are filled in.  false: this block keeps the three-launch path of deep.hip.
-bool deep_block_configure(DeepBlockArgs& a, int force_cl, int force_rq) {
+bool deep_block_configure(DeepBlockArgs& a, int force_cl, int force_rq, int max_wgs) {
+    if (max_wgs > 128) max_wgs = 128;
     if (a.B < 1 || a.H < 1 || a.L < 1 || a.L > 128 || a.C % a.H || (a.C & 15)) return false;
     if (a.H > 8 || (a.H & (a.H - 1))) return false;                      // the heads are the output slabs: 1, 2, 4 or 8
     const int d = a.C / a.H;
@@ -630,6 +631,7 @@ bool deep_block_configure(DeepBlockArgs& a, int force_cl, int force_rq) {
     // Row groups: above 32 tokens a workgroup stages 32-row groups of its K slice instead of all tokens (fewer, wider K slices: the partial
     // q | k | v rows that cross the cluster shrink with the slice count -- at [128 x 512] 16 slices were 12.6 MB of hand-off traffic per block)
     int rq_want = force_rq > 0 ? force_rq : (LP <= 32 ? 1 : (LP / 32 >= 4 ? 4 : LP / 32));
+    while (rq_want & (rq_want - 1)) rq_want &= rq_want - 1;             // a power of two (the kernel indexes the cluster with shifts and masks): LP = 96 -> 2 groups of 48 rows
     for (int RQ = rq_want; RQ >= 1; RQ /= 2) {
         if (LP % (16 * RQ)) continue;
         int best = 0;
@@ -639,7 +641,7 @@ bool deep_block_configure(DeepBlockArgs& a, int force_cl, int force_rq) {
             if (a.C % KSN) continue;
             const int CS = a.C / KSN;
             if (CS < 16 || CS > 128 || (CS & (CS - 1)) || CS % a.gs || CS / a.gs > BLK_MAX_NG) continue;
-            if ((long)a.B * a.H * CL > 128) continue;                          // all workgroups resident together, on half the chip
+            if ((long)a.B * a.H * CL > max_wgs) continue;                      // all workgroups resident together, on half of the CUs the launch may use (<= 128)
             int ncp = CL > nqt ? CL / nqt : 1;                               // column parts: one stage-3 item per workgroup where the cluster allows,
             while (a.C / ncp > 256) ncp *= 2;                                 // at most 256 columns per item (two column tiles per wave)
             if (a.C % ncp) continue;
@@ -661,9 +663,20 @@ bool deep_block_configure(DeepBlockArgs& a, int force_cl, int force_rq) {
         while (a.C / a.ncp > 256) a.ncp *= 2;
         a.ncols = a.C / a.ncp;
         a.rows_per = 2 * ((LP / 2 + best - 1) / best);                       // row PAIRS are dealt to the workgroups
+        if (!deep_block_launchable(a)) continue;                            // (the ONE statement of what the kernel can run: also used by the launcher and the host self-test)
         return true;
     }
     return false;
+}
+
+// What k_deep_block can run: power-of-two cluster / row groups / K slices (blk & (CL - 1), cl_shift = ctz(CL) in the kernel), whole
+// 16-row tiles per row group, the residency bound of the in-launch hand-offs, column parts of whole 16-column tiles.  Pointers are the launcher's business.
+bool deep_block_launchable(const DeepBlockArgs& a) {
+    if (a.CL < 1 || (a.CL & (a.CL - 1)) || a.CL > 16 || a.RQ < 1 || (a.RQ & (a.RQ - 1)) || a.KSN < 1 || (a.KSN & (a.KSN - 1)) || a.KSN * a.RQ != a.CL) return false;
+    if (a.CS * a.KSN != a.C || a.CS < 16 || a.CS > 128 || (a.CS & (a.CS - 1))) return false;
+    if (a.RPQ * a.RQ != (a.L + 15) / 16 * 16 || (a.RPQ & 15)) return false;
+    if ((long)a.B * a.H * a.CL > 128 || a.ncols > 256 || (a.ncols & 15) || a.ncols * a.ncp != a.C) return false;
+    return deep_block_smem_bytes(a) <= 160 * 1024;
 }
 
 size_t deep_block_part_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.KSN * ((a.L + 15) / 16 * 16) * 3 * a.C * 2; }   // 8-byte {data, tag} granules, rows padded to 16
@@ -673,10 +686,7 @@ size_t deep_block_stg_floats(const DeepBlockArgs& a) { return (size_t)a.B * a.H 
 hipError_t launch_deep_block(const DeepBlockArgs& a0, hipStream_t s) {
     DeepBlockArgs a = a0;
     const int d = a.C / a.H;
-    if (a.CL < 1 || (a.CL & (a.CL - 1)) || a.CL > 16 || a.RQ < 1 || (a.RQ & (a.RQ - 1)) || a.KSN * a.RQ != a.CL || a.CS * a.KSN != a.C || a.CS < 16 || a.CS > 128)
-        return hipErrorInvalidValue;
-    if (a.RPQ * a.RQ != (a.L + 15) / 16 * 16 || (a.RPQ & 15)) return hipErrorInvalidValue;
-    if ((long)a.B * a.H * a.CL > 128 || a.ncols > 256 || (a.ncols & 15) || a.ncols * a.ncp != a.C) return hipErrorInvalidValue;
+    if (!deep_block_launchable(a)) return hipErrorInvalidValue;
     if (!a.part || !a.qkv || !a.cnt || !a.fault || !a.x.p || !a.out || (a.RQ > 1 && !a.stg)) return hipErrorInvalidValue;
     a.stg_bytes = (unsigned)(deep_block_stg_floats(a) * 4);
     a.ksn_shift = __builtin_ctz(a.KSN);

@@ -681,31 +681,17 @@ hipError_t attn_init_attrs() {
     if ((e = att_attr<32, 1, 4, 2>()) != hipSuccess) return e;
     if ((e = att_attr<64, 4, 2, 2>()) != hipSuccess) return e;
     if ((e = att_attr<64, 1, 4, 2>()) != hipSuccess) return e;
-    return attn_b3_init_attrs();
+    return hipSuccess;
 }
 
 int g_attn_qb_default = 1;    // QK^T on the bf16 pipe (d = 16 / 32; d = 64 only when asked for) unless MTV_ATT_QB / mtv_debug_attention_qb say otherwise
 int g_attn_qb_force = -1;     // mtv_debug_attention_qb: -1 = environment / default, 0 off, 1 on
-int g_attn_b3_mode = -2;        // -2: not yet read from the environment
-int g_attn_b3_min_keys = 256;
 
 hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     const int d = a.C / a.H;
-    // The split-bf16 core (attn_b3.hip) is parity-green and OFF by default: measured 0-40 % slower than this exact-f32 core
-    // at every shape of the step, of the 8-clip batch and of the 512x512 geometry (profiles/r03_attention_b3.txt: with the
-    // products on the bf16 pipe the key loop is bound by its VALU work, which the split enlarges).  MTV_ATT_B3=1 (or
-    // mtv_debug_attention_b3) forces it onto every eligible launch, -1 onto segments of >= MTV_ATT_B3_MIN keys.
-    if (g_attn_b3_mode == -2) {
-        g_attn_b3_mode = 0;
-        if (const char* e = getenv("MTV_ATT_B3")) g_attn_b3_mode = atoi(e) == 0 ? 0 : (atoi(e) == 1 ? 1 : -1);
-        if (const char* e = getenv("MTV_ATT_B3_MIN")) g_attn_b3_min_keys = atoi(e);
-    }
-    if (g_attn_b3_mode != 0 && attn_b3_eligible(a)) {
-        int maxk = 0;
-        for (int i = 0; i < a.nseg; ++i) maxk = a.seg_len[i] > maxk ? a.seg_len[i] : maxk;
-        if (g_attn_b3_mode == 1 || maxk >= g_attn_b3_min_keys) return launch_attention_b3(a, s);
-    }
+    // (round 3's all-bf16 split core k_attention_b3 -- parity-green, 0-40 % slower at every shape -- left the product in round 6:
+    // tools/experiments/r03_attn_b3.hip, profiles/r03_attention_b3.txt; its QK^T half lives on here as QB = 1)
     // Workgroup shape: QW query tiles (16 queries each) x KSP key parts of every key block.
     //   long segments : 4 x 2 (8 waves, 2 per SIMD.  Not for overlap -- f32 MFMA time and softmax VALU time ADD on a SIMD,
     //                   tools/ubench/mfma_valu -- but to share one K/V staging among 64 queries)

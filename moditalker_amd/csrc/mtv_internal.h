@@ -462,13 +462,7 @@ hipError_t attn_init_attrs();
 hipError_t launch_gn_stats(const StatsArgs& a, hipStream_t s);
 hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
-// split-bf16 attention core (attn_b3.hip): the UNet's self-attention launches with head dim 16 / 32 / 64
-bool attn_b3_eligible(const AttnArgs& a);
-hipError_t launch_attention_b3(const AttnArgs& a, hipStream_t s);
-hipError_t attn_b3_init_attrs();
 extern int g_attn_qb_default, g_attn_qb_force;   // k_attention<..., QB>: QK^T on the bf16 matrix pipe (kernels.hip)
-extern int g_attn_b3_mode;          // -1 auto (segments of >= g_attn_b3_min_keys keys), 0 never, 1 every eligible launch (mtv_debug_attention_b3 / MTV_ATT_B3)
-extern int g_attn_b3_min_keys;
 // deep levels (deep.hip)
 struct DeepTile { int RT, NT; };                 // k_deep_conv<RT, NT>: 16 RT rows x 16 NT columns per workgroup
 size_t deep_weight_floats(const DeepArgs& a, int NT);
@@ -486,8 +480,9 @@ bool deep_attn_configure(DeepAttnArgs& a);                // fills HPW / NC / gr
 hipError_t launch_deep_attn(const DeepAttnArgs& a, hipStream_t s);
 hipError_t deep_init_attrs();
 // whole attention block of a deep level in one launch (block.hip)
-bool deep_block_configure(DeepBlockArgs& a, int force_cl = 0, int force_rq = 0);   // picks the cluster size (force_cl > 0: that one or nothing); false: keep the three-launch path
+bool deep_block_configure(DeepBlockArgs& a, int force_cl = 0, int force_rq = 0, int max_wgs = 128);   // picks the cluster size (force_cl > 0: that one or nothing); false: keep the three-launch path
 size_t deep_block_smem_bytes(const DeepBlockArgs& a);
+bool deep_block_launchable(const DeepBlockArgs& a);       // the configuration checks shared by deep_block_configure, launch_deep_block and mtv_selftest_block
 size_t deep_block_part_floats(const DeepBlockArgs& a);    // scratch sizes of a configured block
 size_t deep_block_qkv_floats(const DeepBlockArgs& a);
 size_t deep_block_stg_floats(const DeepBlockArgs& a);

@@ -199,6 +199,7 @@ static bool table_matches_formula(const std::vector<int>& h, int ntaps, bool upm
 // plan builder
 // =====================================================================================
 static int g_deep_mode = -1;       // mtv_debug_deep: -1 = MTV_DEEP / default (on), 0 = every conv on k_conv, 1 = on
+static int g_resident_override = 0; // mtv_debug_resident_cus: > 0 = contexts created afterwards plan for that many co-resident CUs
 static int g_deep_opts = -1;       // mtv_debug_deep_options: -1 = the MTV_DEEP_* environment / defaults, else a bit mask (MTV_DEEP_OPT_*)
 static bool deep_opt(int bit, const char* env, bool dflt) {
     if (g_deep_opts >= 0) return (g_deep_opts & bit) != 0;
@@ -427,7 +428,8 @@ struct Builder {
                 nslices = ap->second->a.nhg; nwg = ntile * nslices; lastN = ap->second->a.C;
             }
             // (the polling slice waits for workgroups of the same launch: all of them must be resident together)
-            if (fn && tagged_inlaunch && (!tile_ok || nwg > 256 || nslices < 2 || nslices > 8)) fn = nullptr;
+            // -> grid <= the CUs this context may count on (mtv_ctx::resident_cus); otherwise the finalize pass
+            if (fn && tagged_inlaunch && (!tile_ok || nwg > std::min(256, c->resident_cus) || nslices < 2 || nslices > 8)) fn = nullptr;
         }
         if (fn) {
             fn->out = o.p;
@@ -807,7 +809,8 @@ struct Builder {
             static const long max_lc = []() { const char* e = getenv("MTV_BLOCK_MAX_LC"); return e ? atol(e) : 128L * 256; }();
             const bool pays = L.L <= max_l || (long)L.L * C <= max_lc || deep_opt(MTV_DEEP_OPT_BLOCK_ALL, "MTV_DEEP_BLOCK_ALL", false);
             static const int force_rq = []() { const char* e = getenv("MTV_BLOCK_RQ"); return e ? atoi(e) : 0; }();
-            if (pays && (deep_block_configure(ba, force_cl, force_rq) || ((force_cl || force_rq) && deep_block_configure(ba, 0, 0)))) {
+            const int max_wgs = std::min(128, c->resident_cus / 2);        // all workgroups of the launch resident together, on half of what the launch may use
+            if (pays && (deep_block_configure(ba, force_cl, force_rq, max_wgs) || ((force_cl || force_rq) && deep_block_configure(ba, 0, 0, max_wgs)))) {
                 Tens out;
                 out.lvl = lvl; out.C = C; out.ks = H;
                 out.slab = (unsigned)((size_t)deep_clips() * L.L * C);
@@ -1544,6 +1547,15 @@ int ctx_init_common(mtv_ctx* c) {
     HIPCHK(attn_init_attrs());
     HIPCHK(deep_init_attrs());
     HIPCHK(deep_block_init_attrs());
+    {   // Residency of the in-launch hand-offs (ADVICE r5 / VERDICT r5 item 6): their polls wait for workgroups of the SAME launch, which is only
+        // live when the whole grid is resident together -- one 512-thread workgroup of those kernels per CU, so the bound is the CU count the
+        // launch can use: a CPX / DPX partition reports fewer CUs here; a CU-masked stream is checked per call (check_stream_residency).
+        int ncu = 0;
+        HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device));
+        static const int env_cus = []() { const char* e = getenv("MTV_RESIDENT_CUS"); return e ? atoi(e) : 0; }();
+        const int want = g_resident_override > 0 ? g_resident_override : env_cus;
+        c->resident_cus = want > 0 ? std::min(want, ncu > 0 ? ncu : want) : (ncu > 0 ? ncu : 256);
+    }
     if (!c->fault_h) {     // device-side fault word (k_deep_block: a hand-off wait that timed out), host-mapped: checked without a copy
         HIPCHK(hipHostMalloc((void**)&c->fault_h, 64, hipHostMallocMapped));
         *c->fault_h = 0;
@@ -1732,11 +1744,33 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
 
 }  // extern "C"
 
+// test hook (mtv_debug_arm_fault): what a timed-out poll does -- the same system-scope store to the host-mapped fault word
+__global__ void k_debug_raise_fault(int* fault) { __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+static const char* fault_text() {
+    return "an in-launch hand-off timed out (a poll inside k_deep_block, or the tagged completion of a deep tensor inside k_deep_conv / k_deep_attn, waited "
+           "2^21 retries for workgroups of its own launch): results of that call and of every call since are invalid -- destroy this context.  The launch was "
+           "not co-resident (CU-masked queue, partitioned device, another stream's kernel on the same CUs?): MTV_RESIDENT_CUS=<n> plans for n CUs, "
+           "MTV_DEEP_NO_BLOCK=1 + MTV_DEEP_FIN_PASS=1 select the forms without in-launch hand-offs";
+}
+
+// A stream created with a CU mask (hipExtStreamCreateWithCUMask) runs its launches on fewer CUs than the device reports: a plan whose hand-off
+// grids were sized for more must not be replayed there (its polls would depend on dispatch order for progress).
+static int check_stream_residency(mtv_ctx* c, hipStream_t s) {
+    uint32_t mask[32] = {0};
+    if (hipExtStreamGetCUMask(s, 32, mask) != hipSuccess) { (void)hipGetLastError(); return MTV_OK; }     // (no mask to read: the device's CU count stands)
+    int n = 0;
+    for (uint32_t m : mask) n += __builtin_popcount(m);
+    if (n > 0 && n < c->resident_cus)
+        return fail(MTV_ERR_STATE, "the stream's CU mask leaves " + std::to_string(n) + " CUs but this context planned its in-launch hand-offs for " +
+                                   std::to_string(c->resident_cus) + ": create the context with MTV_RESIDENT_CUS=" + std::to_string(n) + " (or mtv_debug_resident_cus) first");
+    return MTV_OK;
+}
+
 int check_ready(mtv_ctx* c, int batch) {
     if (!c) return fail(MTV_ERR_INVALID, "null context");
     if (c->fault_h && *(volatile int*)c->fault_h)
-        return fail(MTV_ERR_STATE, "an in-launch hand-off of k_deep_block timed out in an earlier call (results since then are invalid): destroy this context; "
-                                   "MTV_DEEP_NO_BLOCK=1 selects the three-launch attention block");
+        return fail(MTV_ERR_STATE, fault_text());
     if (batch < 1 || batch > c->cfg.max_batch) return fail(MTV_ERR_STATE, "batch outside [1, max_batch]");
     const int miss = mtv_weights_missing(c);
     if (miss) {
@@ -1800,6 +1834,7 @@ int mtv_forward(mtv_ctx* c, const float* x, const float* cond, const float* imag
     if (!x || !cond || !image_cond || !timesteps || !eps_out) return fail(MTV_ERR_INVALID, "null tensor pointer");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
+    if ((rc = check_stream_residency(c, s)) != MTV_OK) return rc;
     Plan* p = nullptr;
     if ((rc = get_plan(c, batch, MODE_FORWARD, &p)) != MTV_OK) return rc;
     if ((rc = autotune(c, p, s)) != MTV_OK) return rc;
@@ -1812,6 +1847,7 @@ int mtv_forward(mtv_ctx* c, const float* x, const float* cond, const float* imag
         HIPCHK(hipGraphLaunch(p->g_forward, s));
     }
     HIPCHK(hipMemcpyAsync(eps_out, c->eps, (size_t)batch * c->cfg.out_channels * c->lv[0].L * 4, hipMemcpyDeviceToDevice, s));
+    if (c->debug_fault_armed) { c->debug_fault_armed = false; hipLaunchKernelGGL(k_debug_raise_fault, dim3(1), dim3(1), 0, s, c->fault_d); HIPCHK(hipGetLastError()); }
     return MTV_OK;
 }
 
@@ -1900,6 +1936,7 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
     }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(c->device));
+    if ((rc = check_stream_residency(c, s)) != MTV_OK) return rc;
     Plan* p[2] = {nullptr, nullptr};
     for (int par = 0; par < 2; ++par) {
         if ((rc = get_plan(c, batch, par ? MODE_STEP1 : MODE_STEP0, &p[par])) != MTV_OK) return rc;
@@ -1917,19 +1954,21 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
         // every graph this context can need is captured by its FIRST call (the tail of a later call must never pay a capture)
         for (int par = 0; par < 2; ++par)
             if (!p[par]->g_forward && (rc = capture(c, p[par], &p[par]->g_forward)) != MTV_OK) return rc;
-        if (M >= 2) {
-            hipGraphExec_t& gm = c->multi[{batch, M}];
+        if (M >= 2 && n_steps >= M) {            // (captured by the first call that can use it: a 4-step call never pays for ~1.2k kernel nodes -- ADVICE r5)
+            auto mit = c->multi.find({batch, M});
+            if (mit == c->multi.end()) mit = c->multi.emplace(std::make_pair(batch, M), (hipGraphExec_t) nullptr).first;
+            hipGraphExec_t& gm = mit->second;
             if (!gm) {
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
                 int rcc = MTV_OK;
                 for (int k = 0; k < M && rcc == MTV_OK; ++k) rcc = run_ops(c, p[k & 1], c->cap_stream);
                 const hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
-                if (rcc != MTV_OK) { if (g) (void)hipGraphDestroy(g); return rcc; }
-                if (e != hipSuccess) return fail(MTV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+                if (rcc != MTV_OK) { if (g) (void)hipGraphDestroy(g); c->multi.erase(mit); return rcc; }
+                if (e != hipSuccess) { c->multi.erase(mit); return fail(MTV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
                 const hipError_t e2 = hipGraphInstantiate(&gm, g, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(g);
-                if (e2 != hipSuccess) { gm = nullptr; return fail(MTV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
+                if (e2 != hipSuccess) { c->multi.erase(mit); return fail(MTV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2)); }
             }
             for (; n_steps - i0 >= M; i0 += M) HIPCHK(hipGraphLaunch(gm, s));     // (M is even: the next step is an even one again)
         }
@@ -1944,8 +1983,30 @@ int mtv_ddim_sample(mtv_ctx* c, float* x_io, const float* cond, const float* ima
         }
     }
     HIPCHK(hipMemcpyAsync(x_io, c->xin, (size_t)batch * 4 * c->lv[0].L * 4, hipMemcpyDeviceToDevice, s));
+    if (c->debug_fault_armed) { c->debug_fault_armed = false; hipLaunchKernelGGL(k_debug_raise_fault, dim3(1), dim3(1), 0, s, c->fault_d); HIPCHK(hipGetLastError()); }
     return MTV_OK;
 }
+
+/* include/mtv_hip.h: the fault word of the in-launch hand-offs, readable at any time; meaningful for a call once the stream it ran on has drained */
+int mtv_check_fault(mtv_ctx* c) {
+    if (!c) return fail(MTV_ERR_INVALID, "null context");
+    if (c->fault_h && *(volatile int*)c->fault_h) return fail(MTV_ERR_STATE, fault_text());
+    return MTV_OK;
+}
+
+int mtv_debug_arm_fault(mtv_ctx* c) {
+    if (!c || !c->fault_d) return fail(MTV_ERR_INVALID, "null context");
+    c->debug_fault_armed = true;
+    return MTV_OK;
+}
+
+int mtv_debug_resident_cus(int n) {
+    if (n < 0 || n > 4096) return fail(MTV_ERR_INVALID, "resident CUs must be 0 (the device's count / MTV_RESIDENT_CUS) or a positive count");
+    g_resident_override = n;
+    return MTV_OK;
+}
+
+int mtv_resident_cus(const mtv_ctx* c) { return c ? c->resident_cus : fail(MTV_ERR_INVALID, "null context"); }
 
 static int profile_plan(mtv_ctx* c, int batch, int mode, int iters, mtv_op_time* out, int cap, int* n_out, hipStream_t s) {
     int rc = check_ready(c, batch);
@@ -2198,8 +2259,8 @@ int mtv_selftest_block(int tokens, int channels, int heads, int batch) {
         a.B = batch; a.L = tokens; a.C = channels; a.H = heads; a.gs = channels / 32; a.x.ks = ks; a.r = 1; a.t = 1;
         if (!deep_block_configure(a, 0, 0)) return 1;
         const int d = channels / heads, NQ = 3 * d, LP = (tokens + 15) / 16 * 16;
-        if (a.KSN * a.RQ != a.CL || a.CS * a.KSN != channels || a.CS % a.gs || a.RPQ * a.RQ != LP || (a.RPQ & 15)) return 2;
-        if ((long)batch * heads * a.CL > 128 || deep_block_smem_bytes(a) > 160 * 1024) return 3;
+        if (!deep_block_launchable(a)) return 2;                                 // exactly what launch_deep_block checks
+        if (a.CS % a.gs) return 3;
         if (a.ncols * a.ncp != channels || a.ncols > 256 || (a.ncols & 15) || a.nqt * 16 != LP) return 4;
         // stage 2: every row pair below L dealt to exactly one workgroup
         std::vector<int> seen(LP / 2, 0);
@@ -2245,12 +2306,6 @@ int mtv_debug_deep(int mode) {
 int mtv_debug_deep_options(int mask) {
     if (mask < -1 || mask > 127) return fail(MTV_ERR_INVALID, "mask must be -1 (environment / defaults) or a combination of MTV_DEEP_OPT_*");
     g_deep_opts = mask;
-    return MTV_OK;
-}
-
-int mtv_debug_attention_b3(int mode) {
-    if (mode < -1 || mode > 1) return fail(MTV_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (every eligible launch)");
-    g_attn_b3_mode = mode;
     return MTV_OK;
 }
 

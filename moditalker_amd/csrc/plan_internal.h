@@ -179,6 +179,10 @@ struct mtv_ctx {
     bool accounting = false;
     int* fault_h = nullptr;                      // host-mapped fault word of the in-launch hand-offs (block.hip) and its device address
     int* fault_d = nullptr;
+    bool debug_fault_armed = false;              // mtv_debug_arm_fault: the next forward / sampler call ends with a launch that raises the fault word
+    int resident_cus = 256;                      // CUs a launch of this context may count on being resident TOGETHER (ctx_init_common: the device's
+                                                 // multiProcessorCount, or mtv_debug_resident_cus / MTV_RESIDENT_CUS): bounds every grid whose workgroups
+                                                 // wait for each other inside the launch (k_deep_block clusters, tagged completion of deep tensors)
     float* staging = nullptr;
     size_t staging_floats = 0;
     // split-bf16 copies of conv / GEMM weight matrices (k_conv_x3): W [K][ld] f32 -> three bf16 planes, rebuilt after weight loads

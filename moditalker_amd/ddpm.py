@@ -176,7 +176,7 @@ class DDPM(nn.Module):
 
     # ------------------------------------------------------------------ the hot loop
     @torch.no_grad()
-    def _run_ddim(self, x_init, cond, image_cond, pairs, noise):
+    def _run_ddim(self, x_init, cond, image_cond, pairs, noise, strict=None):
         um = self._unet()
         if um is None:
             raise TypeError("DDPM.sample drives the HIP denoiser: `model` must be moditalker_amd's "
@@ -207,10 +207,11 @@ class DDPM(nn.Module):
             _lib.check(_lib.load().mtv_ddim_sample(ctx, x.data_ptr(), cf.data_ptr(), icf.data_ptr(), icf.shape[2],
                                                    noise.data_ptr() if n_draws else None, int(noise.shape[0]),
                                                    steps, len(pairs), B, C.c_void_p(stream)), "mtv_ddim_sample")
+            um.after_call(dev, strict)
         return x
 
     @torch.no_grad()
-    def ddim_sample(self, shape, cond, image_cond, context=None, clip_denoised=True, noise=None):
+    def ddim_sample(self, shape, cond, image_cond, context=None, clip_denoised=True, noise=None, strict=None):
         # ddpm.py:362-404; noise[0] = x_T, noise[1:] = in-loop draws
         dev = self.betas.device
         if noise is None:
@@ -219,11 +220,11 @@ class DDPM(nn.Module):
         else:
             x_T, rest = noise[0], noise[1:]
         assert clip_denoised, "the reference always clamps x0 (ddpm.py:384)"
-        return self._run_ddim(x_T, cond, image_cond, self._time_pairs(), rest)
+        return self._run_ddim(x_T, cond, image_cond, self._time_pairs(), rest, strict=strict)
 
     @torch.no_grad()
     def ddim_sample_noised_start(self, shape, x_start, cond, image_cond, context=None, clip_denoised=True,
-                                 ratio_=None, fixed_noise=False, noise=None):
+                                 ratio_=None, fixed_noise=False, noise=None, strict=None):
         # ddpm.py:407-454
         t = torch.tensor([int(self.num_timesteps * ratio_)], device=x_start.device).long()
         if noise is not None:
@@ -233,14 +234,17 @@ class DDPM(nn.Module):
                 torch.manual_seed(1004)
             q_noise, rest = torch.randn_like(x_start).contiguous(), None
         x_noisy = self.q_sample(x_start=x_start, t=t, noise=q_noise.to(x_start.device))
-        return self._run_ddim(x_noisy, cond, image_cond, self._time_pairs(ratio_), rest)
+        return self._run_ddim(x_noisy, cond, image_cond, self._time_pairs(ratio_), rest, strict=strict)
 
     @torch.no_grad()
     def sample(self, batch_size=16, cond=None, image_cond=None, context=None, return_intermediates=False,
-               noised_start=None, first_stage_model=None, ratio_=None, fix_noise=False, noise=None):
+               noised_start=None, first_stage_model=None, ratio_=None, fix_noise=False, noise=None, strict=None):
         """ddpm.py:456-484.  Returns [batch_size, channels, L] fp32 on the module's device.
         `noise` (appended kwarg): explicit list/tensor of N(0,1) draws in the reference's draw order
         (initial x_T or q_sample noise first, then one per non-final step).
+        `strict` (appended kwarg; default: the MTV_STRICT environment variable, else off): synchronise the stream and raise MtvError if an
+        in-launch hand-off of this call timed out (include/mtv_hip.h mtv_check_fault) -- the reference's torch ops raise synchronously
+        (unet.py:995-1117); without it the fault surfaces at the caller's next call into the library or at `UNetModel.check_fault()`.
         `return_intermediates` / `first_stage_model`: accepted and unused, exactly like the reference's DDIM branch
         (ddpm.py:473-482 forwards return_intermediates only to the unreachable p_sample_loop)."""
         shape = (batch_size, self.channels, self.image_size)
@@ -249,8 +253,8 @@ class DDPM(nn.Module):
                                       "(sampling_timesteps < timesteps) and is not built")
         if noised_start is not None:
             return self.ddim_sample_noised_start(shape, noised_start, cond, image_cond, context, ratio_=ratio_,
-                                                 fixed_noise=fix_noise, noise=noise)
-        return self.ddim_sample(shape, cond, image_cond, context, noise=noise)
+                                                 fixed_noise=fix_noise, noise=noise, strict=strict)
+        return self.ddim_sample(shape, cond, image_cond, context, noise=noise, strict=strict)
 
     def forward(self, *a, **k):
         raise NotImplementedError("training (p_losses) is outside the MI355X hot path (SURVEY.md section 8)")

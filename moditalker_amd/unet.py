@@ -12,6 +12,7 @@ no PyTorch/CPU fallback: calling forward off-GPU, or without the built library, 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -262,6 +263,27 @@ class UNetModel(nn.Module):
         if missing:
             raise _lib.MtvError(f"{missing} weights missing after upload")
 
+    def check_fault(self):
+        """Raise MtvError if an in-launch hand-off of an earlier call on this module's context timed out (include/mtv_hip.h
+        mtv_check_fault).  Meaningful once the stream those calls ran on has drained: call it after your own synchronisation
+        point (`.cpu()`, `torch.cuda.synchronize()`); it does not synchronise.  No context yet: nothing to check."""
+        if self._ctx is not None:
+            _lib.check(_lib.load().mtv_check_fault(self._ctx), "mtv_check_fault")
+
+    def after_call(self, dev, strict=None):
+        """strict (None: MTV_STRICT=1 in the environment): drain the current stream and check the fault word, so that a call whose
+        result is invalid raises ITSELF, as the reference's synchronous torch ops would."""
+        if strict is None:
+            strict = os.environ.get("MTV_STRICT") == "1"
+        if strict:
+            torch.cuda.current_stream(dev).synchronize()
+            self.check_fault()
+
+    @property
+    def resident_cus(self) -> int:
+        """CUs the context plans its in-launch hand-offs for (0: no context yet)."""
+        return int(_lib.load().mtv_resident_cus(self._ctx)) if self._ctx is not None else 0
+
     def set_eager(self, eager: bool):
         """True: plain kernel launches instead of hipGraph replay (profiling / debugging)."""
         self._eager = bool(eager)
@@ -312,6 +334,7 @@ class UNetModel(nn.Module):
         """x [B,4,L], cond [B,8,L], image_cond [B,4,>=R*R], timesteps [B] -> eps [B,out_channels,L]
         (unet.py:995).  `context` is ignored exactly as the reference ignores it (always None there)."""
         assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
+        strict = kwargs.pop("strict", None)      # (appended option, see after_call; every other kwarg is ignored as in the reference)
         R, T = self.image_size, self.frames
         L = R * R + 2 * T * R
         B = self.check_inputs(x, cond, image_cond)
@@ -328,6 +351,7 @@ class UNetModel(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(_lib.load().mtv_forward(ctx, xf.data_ptr(), cf.data_ptr(), icf.data_ptr(), icf.shape[2],
                                                tt.data_ptr(), out.data_ptr(), B, C.c_void_p(stream)), "mtv_forward")
+            self.after_call(dev, strict)
         return out.type(x.dtype)
 
     def debug_tap(self, name: str, batch: int) -> torch.Tensor:

@@ -56,6 +56,48 @@ def test_sharded_sampling_gloo_world2(n_clips):
     assert sorted(res[0][2] + res[1][2]) == list(range(n_clips))      # every clip sampled exactly once
 
 
+def test_sharded_sampling_gloo_world8_eight_clips_mirrors_configs2():
+    """BASELINE configs[2] at its own width: 8 clips over 8 ranks, one clip each, ONE all_gather (sample.py:267,305 iterate the
+    same clips sequentially on one GPU).  gloo on CPU stands in for RCCL; the sharding / gather code is the same."""
+    world = n_clips = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert [r for r, _, _ in res] == list(range(world))
+    assert all(ok for _, ok, _ in res)                                  # every rank holds all 8 latents, in clip order, bit-equal
+    assert all(calls == [r] for r, _, calls in res)                     # clip i ran on rank i and nowhere else
+
+
+def test_bench_py_eight_rank_dry_run_under_gloo():
+    """bench.py --gpus 8 with MTV_BENCH_DRYRUN=1: eight processes under torch.distributed.run, gloo instead of RCCL, the sampler call
+    replaced by a stub (no GPU here) -- everything else is bench.py's own N > 1 path: rendezvous from the env, barrier-bracketed timed
+    region, per-rank step times gathered, the final all_gather of the latents, MAX over ranks, ONE JSON line on rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MTV_BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    di = d["distributed"]
+    assert di["backend"] == "gloo" and di["world_size_reported"] == 8 and di["latents_gathered"] == 8
+    pr = di["per_rank_ms_per_step"]
+    assert 0 < pr["min"] <= pr["median"] <= pr["max"] <= d["ms_per_step"] * 1.001
+    assert abs(d["value"] - 8 * 6 / (d["ms_per_step"] * 6e-3)) <= 1e-2 * d["value"]      # whole-job aggregate: N K / max-over-ranks time
+
+
 def test_without_process_group_is_a_plain_loop():
     out = sample_clips_sharded(_fake_sample, 3)
     assert all(torch.equal(out[i], _fake_sample(i)) for i in range(3))

@@ -254,7 +254,9 @@ def test_deep_level_row_tables_match_im2col_tables(R, T, levels):
 
 @pytest.mark.parametrize("tokens,channels,heads,batch", [(32, 512, 8, 1), (32, 512, 8, 2), (128, 512, 8, 1), (128, 512, 8, 2), (128, 256, 8, 1),
                                                          (128, 128, 8, 2), (72, 256, 8, 1), (60, 128, 8, 2), (15, 128, 2, 1), (128, 64, 2, 1),
-                                                         (32, 32, 2, 2), (96, 512, 8, 1), (18, 512, 8, 1)])
+                                                         (32, 32, 2, 2), (96, 512, 8, 1), (18, 512, 8, 1),
+                                                         # 81..96 tokens: LP / 32 = 3 row groups is not a launchable cluster -> two groups of 48 rows
+                                                         (96, 256, 8, 2), (91, 256, 8, 2), (96, 128, 8, 1), (80, 512, 8, 1), (112, 256, 8, 1)])
 def test_one_launch_attention_block_work_split(tokens, channels, heads, batch):
     """csrc/block.hip, k_deep_block (an attention block of a deep level in one launch): the cluster configuration for the base model's shapes,
     the test models' and ragged token counts -- grid within the residency bound, LDS within 160 KB, every row pair of stage 2 and every

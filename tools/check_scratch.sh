@@ -3,7 +3,7 @@
 # A scratch access is a vector memory operation: it waits like one (`s_waitcnt vmcnt`) -- inside a prologue that has weight requests in
 # flight that is a wait for all of them -- so new entries in this list deserve a look at the source.
 cd "$(dirname "$0")/../moditalker_amd/csrc"
-for f in kernels conv conv_x3 lin attn_b3 deep ae xattn; do
+for f in kernels conv conv_x3 lin deep block ae xattn; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -S --cuda-device-only $f.hip -o /tmp/chk_$f.s 2>/dev/null || { echo "$f.hip: compile failed"; continue; }
     python3 - /tmp/chk_$f.s $f <<'PY'
 import re, sys

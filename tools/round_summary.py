@@ -36,8 +36,7 @@ if b:
         print(f"| family `{k}` | {v['ms_per_step']} ms per step, {v['launches']} launches" + (f", {v['tflops']} TFLOP/s" if v.get("tflops") else "") +
               (f", {v['algorithmic_GBs']} GB/s algorithmic" if v.get("algorithmic_GBs") else "") + " |")
     if c:
-        bt = c.get("best_threads") or {}
-        print(f"| `cpu_baseline` | {c['value']} steps/s at {c['cores']} threads = physical cores ({c['sample'][:60]}...); best of the thread probe: {bt.get('value')} steps/s at {bt.get('threads')} threads ({bt.get('steps')} steps) |")
+        print(f"| `cpu_baseline` | {c['value']} steps/s at {c['cores']} threads ({c['sample'][:70]}...); probe s/step {c.get('thread_probe_s_per_step')}; leg wall {c.get('leg_wall_s')} s |")
     print(f"| `gpu_active_s` | {b.get('gpu_active_s')} |")
     hv = (r.get("hbm_view") or {}).get("deep_levels")
     if hv:

@@ -636,6 +636,9 @@ static int do_block(bool timing) {
     bad += run_block(8, 4, 128, 8, 1, 2, 1, 0, false);
     bad += run_block(6, 3, 256, 8, 0, 1, 1, 0, false);        // ragged planes 36 | 18 | 18 (72 tokens: 5 query tiles)
     bad += run_block(6, 3, 256, 8, 1, 2, 2, 0, false);
+    bad += run_block(8, 2, 256, 8, 1, 2, 1, 0, false);        // 96 tokens (LP / 32 = 3 row groups is not launchable -- two groups of 48 rows)
+    bad += run_block(8, 2, 512, 8, 0, 4, 2, 0, false);        // ... per plane (64 | 16 | 16), two clips
+    bad += run_block(7, 3, 256, 8, 1, 1, 2, 0, false);        // 91 tokens (padded to 96)
     bad += run_block(3, 1, 128, 2, 0, 1, 1, 0, false);        // 15 tokens, d = 64, two heads
     bad += run_block(8, 4, 64, 2, 0, 2, 1, 0, false);         // groups of 2 channels (narrow test model at a small geometry)
     bad += run_block(4, 2, 32, 2, 1, 1, 2, 0, false);         // groups of 1 channel, d = 16
