@@ -179,6 +179,9 @@ int mtv_debug_force_win(int mt, int nt);
  * unet.py:234,253) on k_conv_pw<mt, ntw> (16 mt rows normalised once into LDS, 8 waves side by side along 128 ntw output channels, ntw = 1 | 2,
  * whole K per wave; csrc/deep.hip) instead of the tuned choice; mt = 0 switches it off again. */
 int mtv_debug_force_pw(int mt, int ntw);
+/* ... with `waves` of the 8 waves multiplying (8, or 6 / 4 / 2 at ntw = 1): the column tile is 16 ntw waves wide, so that e.g. qkv at N = 384 is
+ * 4 tiles of 96 columns (256 workgroups with 32-row tiles) instead of 3 of 128 (192), proj_out at N = 128 two tiles of 64. */
+int mtv_debug_force_pw_waves(int mt, int ntw, int waves);
 /* Testing aid: attention launches issued (or captured) after this call compute QK^T on the bf16 matrix pipe through a three-term
  * split of q and k at f32 accuracy (k_attention<..., QB = 1>: the 8-wave shapes of d = 16 / 32 / 64; PV stays on the f32
  * instruction): 1 on, 0 off, -1 back to the build default / MTV_ATT_QB. */

@@ -1330,7 +1330,7 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
         a.xmap = t.XM;
     }
     if (t.NW == 96) {            // 1x1 kernel of the large levels (deep.hip: k_conv_pw)
-        if (conv_pw_eligible(a, t.MT, t.NT)) return launch_conv_pw(a, t, s);
+        if (conv_pw_eligible(a, t.MT, t.NT, t.KS)) return launch_conv_pw(a, t, s);
         t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);
         t.KS = 1;
         a.KS = 1;

@@ -1500,11 +1500,15 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
 // (ConvArgs::Wnk: lane (j, q) loads W[n][c0 + 4q .. + 3], one 16-byte request per 16-channel chunk and column block), requested
 // between the rows of the transform, and the accumulators go through LDS once so that stores, residual reads and statistics are
 // 16-byte wide.  Workgroup = (clip, row tile, group of 128 NTW columns), 512 threads.
-template <int MT, int NTW>
+// (round 6: NWA = the waves that multiply -- 8, 6, 4 or 2 -- so that the column tile is 16 NTW NWA wide and the grid can be made to FILL the chip:
+// qkv at N = 384 / 768 / 1536 has 3 / 6 / 12 tiles of 128 columns -- 192 workgroups with 32- / 16-row tiles on 256 CUs -- but 4 / 8 / 16 tiles of 96;
+// proj_out at N = 128 / 256 one or two tiles of 128 but 256 workgroups with 64- / 32-column tiles.  The idle waves still stage rows and store.
+// tools/ubench/stage_bench.hip's lean qkv / proj bodies -- 256 workgroups each -- measured 6.8 / 5.1 us where these launches took 8.8 / 6.6-7.2)
+template <int MT, int NTW, int NWA>
 __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
     touch_kernargs<(int)sizeof(ConvArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ROWS = 16 * MT, COLS = 128 * NTW;
+    constexpr int ROWS = 16 * MT, COLS = 16 * NTW * NWA;
     constexpr int G = NTW == 1 ? 8 : 4;                    // weight chunks per register set (two sets: K = 256 is in flight whole at NTW = 1)
     constexpr int MAXR = 8;                                // rows in flight per thread
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1555,7 +1559,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
     // weights: wave w owns the NTW column blocks of 16 that start at n0 + 16 NTW w; lane (j, q) holds, of column block nb, output
     // channel nw0 + NTW j + nb (its NTW channels are consecutive: 4 NTW-float runs per lane in the LDS image below)
     const int nw0 = n0 + 16 * NTW * wave;
-    const bool wave_on = nw0 < a.N;                        // (N is a multiple of 16 NTW: a wave is all in or all out)
+    const bool wave_on = wave < NWA && nw0 < a.N;          // (N is a multiple of 16 NTW: a wave is all in or all out)
     const int nch = K >> 4;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wnk), 0, a.N * K * 4, 0x00020000);
     const int wlane = ((nw0 + NTW * i) * K + 4 * q) * 4;
@@ -1952,8 +1956,11 @@ hipError_t deep_init_attrs() {
     const void* fa[] = {reinterpret_cast<const void*>(&k_deep_attn<16>), reinterpret_cast<const void*>(&k_deep_attn<32>), reinterpret_cast<const void*>(&k_deep_attn<64>),
                         reinterpret_cast<const void*>(&k_conv_win<1, 4>), reinterpret_cast<const void*>(&k_conv_win<1, 2>),
                         reinterpret_cast<const void*>(&k_conv_win<2, 2>),
-                        reinterpret_cast<const void*>(&k_conv_pw<1, 1>), reinterpret_cast<const void*>(&k_conv_pw<1, 2>),
-                        reinterpret_cast<const void*>(&k_conv_pw<2, 1>), reinterpret_cast<const void*>(&k_conv_pw<2, 2>)};
+                        reinterpret_cast<const void*>(&k_conv_pw<1, 1, 8>), reinterpret_cast<const void*>(&k_conv_pw<1, 2, 8>),
+                        reinterpret_cast<const void*>(&k_conv_pw<2, 1, 8>), reinterpret_cast<const void*>(&k_conv_pw<2, 2, 8>),
+                        reinterpret_cast<const void*>(&k_conv_pw<1, 1, 6>), reinterpret_cast<const void*>(&k_conv_pw<2, 1, 6>),
+                        reinterpret_cast<const void*>(&k_conv_pw<1, 1, 4>), reinterpret_cast<const void*>(&k_conv_pw<2, 1, 4>),
+                        reinterpret_cast<const void*>(&k_conv_pw<1, 1, 2>), reinterpret_cast<const void*>(&k_conv_pw<2, 1, 2>)};
     for (const void* f : fa) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -2116,14 +2123,17 @@ hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s) {
 }
 
 // ---- k_conv_pw (ConvTile{MT, NTW, NW = 96, KS = 1, XM = 0}) ----
-static size_t conv_pw_layout(const ConvArgs& a, int MT, int NTW) {
-    const int ROWS = 16 * MT, COLS = 128 * NTW;
+static int conv_pw_waves(int code) { return code == 1 ? 8 : code; }      // ConvTile::KS of a k_conv_pw tile: 1 = all 8 waves multiply, else 6 / 4 / 2
+static size_t conv_pw_layout(const ConvArgs& a, int MT, int NTW, int NWA) {
+    const int ROWS = 16 * MT, COLS = 16 * NTW * NWA;
     const size_t stage = (size_t)ROWS * (a.Cmain + DEEP_PAD) + 384 + 192;          // rows | statistics (doubles) | (mean, rstd)
     const size_t image = (size_t)ROWS * (COLS + 4) + DEEP_FIN_FLOATS;
     return (stage > image ? stage : image) * 4 + 64;
 }
-bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW) {
+bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW, int wcode) {
+    const int NWA = conv_pw_waves(wcode);
     if (!((MT == 1 || MT == 2) && (NTW == 1 || NTW == 2))) return false;       // (NTW = 3 measured slower than 1 and 2 on every shape: not built)
+    if (!(NWA == 8 || (NTW == 1 && (NWA == 6 || NWA == 4 || NWA == 2)))) return false;
     if (!a.Wnk || a.ntaps != 1 || a.nmain != 1 || a.nskip != 0 || a.Cskip != 0 || a.gather || a.gather_skip || a.geo_main || a.geo_skip) return false;
     if (a.out_cm || a.ddim || a.bias_b || a.bias2) return false;
     if ((a.Cmain & 15) || a.Cmain < 64 || a.Cmain > 512 || (512 % (a.Cmain >> 2)) || a.N % (16 * NTW) || a.Lsrc != a.Lout || (a.res && a.Lskip != a.Lout)) return false;
@@ -2131,15 +2141,16 @@ bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW) {
     for (int t = 0; t < a.nstat; ++t)
         if (a.stat[t].coff & 3) return false;
     if ((long)a.N * a.Cmain * 4 >= 0x7F000000L) return false;
-    return conv_pw_layout(a, MT, NTW) <= 160 * 1024;
+    return conv_pw_layout(a, MT, NTW, NWA) <= 160 * 1024;
 }
-size_t conv_pw_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_pw_layout(a, t.MT, t.NT); }
+size_t conv_pw_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_pw_layout(a, t.MT, t.NT, conv_pw_waves(t.KS)); }
 
-template <int MT, int NTW>
+template <int MT, int NTW, int NWA>
 static hipError_t conv_pw_launch_t(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
-    if (!conv_pw_eligible(a, MT, NTW)) return hipErrorInvalidValue;
-    const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT), groups = (a.N + 128 * NTW - 1) / (128 * NTW);
+    if (!conv_pw_eligible(a, MT, NTW, NWA == 8 ? 1 : NWA)) return hipErrorInvalidValue;
+    constexpr int COLS = 16 * NTW * NWA;
+    const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT), groups = (a.N + COLS - 1) / COLS;
     a.KS = 1;
     a.xmap = 0;
     a.tiles_per_b = tiles;
@@ -2148,14 +2159,21 @@ static hipError_t conv_pw_launch_t(const ConvArgs& a0, hipStream_t s) {
     a.inv_tiles_per_b = 1.0f / (float)tiles;
     a.inv_Bt = 1.0f / (float)a.Bt;
     if ((long)a.Bt * groups >= (1L << 21)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_conv_pw<MT, NTW>), dim3((unsigned)(a.Bt * groups)), dim3(DEEP_NTH), conv_pw_layout(a, MT, NTW), s, a);
+    hipLaunchKernelGGL((k_conv_pw<MT, NTW, NWA>), dim3((unsigned)(a.Bt * groups)), dim3(DEEP_NTH), conv_pw_layout(a, MT, NTW, NWA), s, a);
     return hipGetLastError();
 }
 hipError_t launch_conv_pw(const ConvArgs& a, ConvTile t, hipStream_t s) {
-    if (t.MT == 1 && t.NT == 1) return conv_pw_launch_t<1, 1>(a, s);
-    if (t.MT == 1 && t.NT == 2) return conv_pw_launch_t<1, 2>(a, s);
-    if (t.MT == 2 && t.NT == 1) return conv_pw_launch_t<2, 1>(a, s);
-    if (t.MT == 2 && t.NT == 2) return conv_pw_launch_t<2, 2>(a, s);
+    const int nwa = conv_pw_waves(t.KS);
+    if (t.MT == 1 && t.NT == 1 && nwa == 8) return conv_pw_launch_t<1, 1, 8>(a, s);
+    if (t.MT == 1 && t.NT == 2 && nwa == 8) return conv_pw_launch_t<1, 2, 8>(a, s);
+    if (t.MT == 2 && t.NT == 1 && nwa == 8) return conv_pw_launch_t<2, 1, 8>(a, s);
+    if (t.MT == 2 && t.NT == 2 && nwa == 8) return conv_pw_launch_t<2, 2, 8>(a, s);
+    if (t.MT == 1 && t.NT == 1 && nwa == 6) return conv_pw_launch_t<1, 1, 6>(a, s);
+    if (t.MT == 2 && t.NT == 1 && nwa == 6) return conv_pw_launch_t<2, 1, 6>(a, s);
+    if (t.MT == 1 && t.NT == 1 && nwa == 4) return conv_pw_launch_t<1, 1, 4>(a, s);
+    if (t.MT == 2 && t.NT == 1 && nwa == 4) return conv_pw_launch_t<2, 1, 4>(a, s);
+    if (t.MT == 1 && t.NT == 1 && nwa == 2) return conv_pw_launch_t<1, 1, 2>(a, s);
+    if (t.MT == 2 && t.NT == 1 && nwa == 2) return conv_pw_launch_t<2, 1, 2>(a, s);
     return hipErrorInvalidValue;
 }
 

@@ -447,7 +447,7 @@ int conv_win_selftest(int r, int t, bool up, int Lout, int Lsrc);      // host-o
 size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s);
 // k_conv_pw<MT, NTW> (deep.hip): 1x1 conv on identity rows, rows normalised once into LDS, waves side by side along N (ConvTile NW = 96)
-bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW);
+bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW, int wcode = 1);     // wcode = ConvTile::KS of the tile: 1 = all 8 waves multiply, 6 / 4 / 2 = that many (column tile 16 NTW x waves)
 size_t conv_pw_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv_pw(const ConvArgs& a, ConvTile t, hipStream_t s);
 bool conv_lin_eligible(const ConvArgs& a);

@@ -1089,7 +1089,7 @@ struct Builder {
 // LDS-tiled kernel k_conv_lds<WM, WN>; a conv that turns out not to be eligible at launch falls back (launch_conv)
 static int g_force_wm = -1, g_force_wn = 0;
 static int g_force_b3[3] = {-1, 0, 1};       // MTV_FORCE_B3="MT,NT[,KS]" (or mtv_debug_force_b3): every eligible conv on the split-bf16 kernel k_conv_x3<MT, NT>
-static int g_force_pw[2] = {-1, 0};         // MTV_FORCE_PW="MT,NTW" (or mtv_debug_force_pw): every eligible 1x1 conv on k_conv_pw<MT, NTW>
+static int g_force_pw[3] = {-1, 0, 1};         // MTV_FORCE_PW="MT,NTW" (or mtv_debug_force_pw): every eligible 1x1 conv on k_conv_pw<MT, NTW>
 static int g_force_win[2] = {-1, 0};        // MTV_FORCE_WIN="MT,NT" (or mtv_debug_force_win): every eligible 3x3 conv on k_conv_win<MT, NT>
 static int g_force_lin[3] = {-1, 0, 0};     // MTV_FORCE_LIN="MT,NT,NWV" (or mtv_debug_force_lin): every eligible 1x1 conv on k_lin<MT, NT, NWV>
 static void parse_force_b3() {
@@ -1138,10 +1138,12 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
         g_force_pw[0] = 0;
         if (const char* e = getenv("MTV_FORCE_PW")) {
             int x = 0, y = 0;
-            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 1 || x == 2) && (y == 1 || y == 2)) { g_force_pw[0] = x; g_force_pw[1] = y; }
+            int z = 1;
+            const int nf = sscanf(e, "%d,%d,%d", &x, &y, &z);
+            if (nf >= 2 && (x == 1 || x == 2) && (y == 1 || y == 2) && (z == 1 || z == 2 || z == 4 || z == 6)) { g_force_pw[0] = x; g_force_pw[1] = y; g_force_pw[2] = z; }
         }
     }
-    if (g_force_pw[0] > 0 && conv_pw_eligible(a, g_force_pw[0], g_force_pw[1])) { *t = ConvTile{g_force_pw[0], g_force_pw[1], 96, 1, 0}; return; }
+    if (g_force_pw[0] > 0 && conv_pw_eligible(a, g_force_pw[0], g_force_pw[1], g_force_pw[2])) { *t = ConvTile{g_force_pw[0], g_force_pw[1], 96, g_force_pw[2], 0}; return; }
     parse_force_b3();
     if (g_force_b3[0] > 0 && conv_x3_eligible(a) && conv_x3_smem_bytes(a, ConvTile{g_force_b3[0], g_force_b3[1], 48, 1, 0}) <= CONV_X3_MAX_LDS) {
         const int nch32 = a.ntaps * (a.Cmain / 32) + a.Cskip / 32;
@@ -1171,7 +1173,7 @@ int finish_split_k(mtv_ctx* c, Plan* plan) {
         const size_t one = (size_t)B * op->a.Lout * op->a.N;
         size_t ks = 16;
         while (ks > 1 && ks * one * 4 > ((size_t)64 << 20)) ks /= 2;
-        if (op->t.NW != 64 && op->t.NW != 80 && (size_t)op->t.KS > ks) ks = op->t.KS;      // (k_lin's KS is a wave count, k_conv_win never splits K)
+        if (op->t.NW != 64 && op->t.NW != 80 && op->t.NW != 96 && (size_t)op->t.KS > ks) ks = op->t.KS;      // (k_lin's / k_conv_pw's KS is a wave count, k_conv_win never splits K)
         if (ks < 2) continue;                       // never split: needs no slab (the autoencoder's 16384-token GEMMs)
         need = ks * one > need ? ks * one : need;
     }
@@ -1300,12 +1302,12 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
             const bool b3_ok = t.NW == 48 && !(a.B == 1 && a.Lout <= 2048) && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
             const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && (t.XM == 0 || t.XM == 1) && conv_win_eligible(a, t.MT, t.NT);
-            const bool pw_ok = t.NW == 96 && t.KS == 1 && t.XM == 0 && conv_pw_eligible(a, t.MT, t.NT);
+            const bool pw_ok = t.NW == 96 && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 6) && t.XM == 0 && conv_pw_eligible(a, t.MT, t.NT, t.KS);
             const bool shape_ok = tiled_ok || lin_ok || b3_ok || win_ok || pw_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
                                    t.KS >= 1 && t.KS <= 16 && (t.KS & (t.KS - 1)) == 0 && (t.XM == 0 || t.XM == 1));
-            if (!shape_ok || (!tiled_ok && !lin_ok && !b3_ok && !win_ok && !pw_ok && t.NW * t.KS > nchunks) || (!lin_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
+            if (!shape_ok || (!tiled_ok && !lin_ok && !b3_ok && !win_ok && !pw_ok && t.NW * t.KS > nchunks) || (!lin_ok && !pw_ok && t.KS > 1 && ((size_t)t.KS * a.B * a.Lout * a.N > slab_cap || (a.N & 3))) ||
                 (!b3_ok && !win_ok && !pw_ok && conv_smem_bytes(a, t) > 120 * 1024)) {
                 // (a plain entry that a lin-eligible conv only borrowed stays: it may be its twin's; the new measurement goes under "<key> l")
                 if (lin_fallback) { char kl[192]; snprintf(kl, sizeof kl, "%s l", key); snprintf(key, sizeof key, "%s", kl); }
@@ -1447,10 +1449,13 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             // the 1x1 kernel of the large levels (deep.hip, k_conv_pw): rows normalised once into LDS, 8 waves side by side along N
             if (a.ntaps == 1 && (long)a.B * a.Lout >= 256) {
                 for (int MT = 1; MT <= 2; ++MT)
-                    for (int NTW = 1; NTW <= 2; ++NTW) {
-                        if (!conv_pw_eligible(a, MT, NTW)) continue;
-                        const ConvTile t{MT, NTW, 96, 1, 0};
-                        if ((long)a.B * ((a.Lout + 16 * MT - 1) / (16 * MT)) * ((a.N + 128 * NTW - 1) / (128 * NTW)) < 48) continue;
+                    for (int NTW = 1; NTW <= 2; ++NTW)
+                      for (int wc : {1, 6, 4, 2}) {
+                        if (!conv_pw_eligible(a, MT, NTW, wc)) continue;
+                        const ConvTile t{MT, NTW, 96, wc, 0};
+                        const int cols = 16 * NTW * (wc == 1 ? 8 : wc);
+                        if (wc != 1 && a.N % cols) continue;                 // (narrower column tiles only where they divide N: whole tiles, a full grid)
+                        if ((long)a.B * ((a.Lout + 16 * MT - 1) / (16 * MT)) * ((a.N + cols - 1) / cols) < 48) continue;
                         float samp[16];
                         HIPCHK(run(t));
                         for (int w = 0; w < nsamp; ++w) {
@@ -2330,10 +2335,14 @@ int mtv_debug_force_lin(int mt, int nt, int nwv) {
     return MTV_OK;
 }
 
-int mtv_debug_force_pw(int mt, int ntw) {
+int mtv_debug_force_pw(int mt, int ntw) { return mtv_debug_force_pw_waves(mt, ntw, 1); }
+
+int mtv_debug_force_pw_waves(int mt, int ntw, int waves) {
     if (mt == 0) { g_force_pw[0] = 0; return MTV_OK; }
-    if (!((mt == 1 || mt == 2) && (ntw == 1 || ntw == 2))) return fail(MTV_ERR_INVALID, "k_conv_pw tile must be {1, 2} x {1, 2}");
-    g_force_pw[0] = mt; g_force_pw[1] = ntw;
+    if (waves == 8) waves = 1;
+    if (!((mt == 1 || mt == 2) && (ntw == 1 || ntw == 2)) || !(waves == 1 || (ntw == 1 && (waves == 2 || waves == 4 || waves == 6))))
+        return fail(MTV_ERR_INVALID, "k_conv_pw tile must be {1, 2} x {1, 2} with 8 multiplying waves, or {1, 2} x 1 with 6 / 4 / 2");
+    g_force_pw[0] = mt; g_force_pw[1] = ntw; g_force_pw[2] = waves;
     return MTV_OK;
 }
 

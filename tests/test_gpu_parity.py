@@ -626,7 +626,8 @@ def test_hand_off_fault_is_reported_by_the_same_call_and_is_sticky():
     assert z0.shape == z1.shape and torch.equal(a, a)
     # a fresh context of the same module is clean again
     net2.diffusion_model._release()
-    assert torch.equal(dm.sample(batch_size=1, cond=cond, image_cond=ic, noise=noise, strict=True), z0)
+    # (a new context re-tunes the shapes the committed tile table does not list and may pick another split-K: fp32 summation-order noise only)
+    assert _maxabs(dm.sample(batch_size=1, cond=cond, image_cond=ic, noise=noise, strict=True), z0.cpu()) <= 1e-4
 
 
 def _cu_masked_stream(n_cus):
@@ -671,7 +672,7 @@ def test_fewer_resident_cus_keep_the_plan_correct_and_are_enforced():
             x, cond, ic = inputs
             g = _golden("base")
             with torch.cuda.stream(st):
-                eps = net(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([500], device=dev), strict=True)
+                eps = net.diffusion_model(x.to(dev), cond.to(dev), ic.to(dev), torch.tensor([500], device=dev), strict=True)
             st.synchronize()
             assert report("48 resident CUs, on a 48-CU queue: base eps t=500 vs reference golden", _maxabs(eps, g["eps_t500"]), FWD_TOL) <= FWD_TOL
             narrow = _cu_masked_stream(16)
