@@ -577,14 +577,15 @@ def test_window_staged_conv_kernel_vs_reference_golden(mt, nt):
     _forced("mtv_debug_force_win", (mt, nt), (0, 0), f"k_conv_win<{mt},{nt}>", expect)
 
 
-@pytest.mark.parametrize("mt,ntw", [(1, 1), (1, 2), (2, 1), (2, 2)])
-def test_pointwise_conv_kernel_vs_reference_golden(mt, ntw):
-    """k_conv_pw (csrc/deep.hip: the rows of a tile normalised once into LDS, 8 waves side by side along N, weights in [N][K]) forced
-    onto every eligible 1x1 conv (qkv with its GroupNorm, proj_out with residual + statistics): eps of the base UNet vs the reference
-    golden, and a ragged two-clip geometry (partial row tiles, tiles that straddle planes) vs the oracle."""
+@pytest.mark.parametrize("mt,ntw,waves", [(1, 1, 8), (1, 2, 8), (2, 2, 8), (2, 1, 6), (1, 1, 4), (2, 1, 4), (1, 1, 2)])
+def test_pointwise_conv_kernel_vs_reference_golden(mt, ntw, waves):
+    """k_conv_pw<MT, NTW, NWA> (csrc/deep.hip: the rows of a tile normalised once into LDS, NWA of the 8 waves side by side along N -- column
+    tile 16 NTW NWA --, weights in [N][K]) forced onto every eligible 1x1 conv (qkv with its GroupNorm, proj_out with residual + statistics):
+    eps of the base UNet vs the reference golden, and a ragged two-clip geometry (partial row tiles, tiles that straddle planes, partial
+    column tiles) vs the oracle.  The committed table selects the 6- / 4- / 2-wave forms for the B = 1 step (round 6)."""
     def expect(names):
-        assert sum(",96,1]" in n for n in names) >= 20, "the pointwise kernel was not selected"
-    _forced("mtv_debug_force_pw", (mt, ntw), (0, 0), f"k_conv_pw<{mt},{ntw}>", expect)
+        assert sum(f",96,{1 if waves == 8 else waves}]" in n for n in names) >= 20, "the pointwise kernel was not selected"
+    _forced("mtv_debug_force_pw_waves", (mt, ntw, waves), (0, 0, 0), f"k_conv_pw<{mt},{ntw},{waves}>", expect)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -232,8 +232,9 @@ def test_committed_tile_table_is_well_formed():
             assert taps == 9 and (mt, nt) in ((1, 4), (1, 2), (2, 2)) and ks == 1 and N % (16 * nt) == 0, line
             Ls, Lk = int(m.group(3)), int(m.group(4))
             assert xm == (1 if (taps * Cm + Cs) * N >= B * (Ls * Cm + Lk * Cs + L * N) else 0), line
-        elif nw == 96:                    # k_conv_pw<MT, NTW> (csrc/deep.hip): 1x1 on identity rows, whole K per wave
-            assert taps == 1 and mt in (1, 2) and nt in (1, 2) and ks == 1 and xm == 0 and N % (16 * nt) == 0 and Cs == 0 and 64 <= Cm <= 512, line
+        elif nw == 96:                    # k_conv_pw<MT, NTW, NWA> (csrc/deep.hip): 1x1 on identity rows, whole K per wave; KS = multiplying waves (1 = all 8)
+            assert taps == 1 and mt in (1, 2) and nt in (1, 2) and xm == 0 and N % (16 * nt) == 0 and Cs == 0 and 64 <= Cm <= 512, line
+            assert ks == 1 or (nt == 1 and ks in (2, 4, 6) and N % (16 * ks) == 0), line       # narrower column tiles only where they divide N
         elif nw == 32:                    # k_conv_lds<WM, WN>
             assert mt in (2, 4) and nt in (2, 4, 8) and ks == 1, line
         else:                             # k_conv<MT, NT, NW>

@@ -103,6 +103,11 @@ timeout 300 $DB block time > $O/r${NN}_deep_block.txt 2>&1
 #      launches), with stamps (the r04_conv_win_stamps.txt / r04_conv_pw_stamps.txt of round 4 are these commands run across kernel versions)
 (timeout 120 $DB win 20 32 16 128; timeout 120 $DB win 20 16 8 256) > $O/r${NN}_conv_win_chain.txt 2>&1
 (timeout 120 $DB pw 32 16 128 384; timeout 120 $DB pw 16 8 256 768; timeout 120 $DB pw 16 8 512 1536) > $O/r${NN}_conv_pw_chain.txt 2>&1
+# 10c. round 6: one real level-0 stage (in1) as eight launches and as ONE persistent launch, same phase bodies, both checked against double CPU math
+#      (tools/ubench/stage_bench.hip): us per stage of each form, the in-launch edges' anatomy, per-phase cycles
+if [ -x tools/ubench/stage_bench ]; then
+    (timeout 300 tools/ubench/stage_bench check | tail -9; timeout 200 tools/ubench/stage_bench time 12) > $O/r${NN}_stage_bench.txt 2>&1
+fi
 # 11. one page of numbers, written by a script from the files above (no hand-typed figures)
 python tools/round_summary.py $NN $O > $O/r${NN}_summary.md 2>$O/summary.err
 rm -rf $O/kt $O/ktae $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE

@@ -159,18 +159,40 @@ __device__ __forceinline__ void tile_epilogue(const float* red, int nparts, cons
 
 // -------------------------------------------------------------------------------------------------------------------- conv3x3 phase
 // workgroup = (image row y of a plane = 32 tokens, 32 output channels); wave w = input channels [16 w, 16 w + 16) of all nine taps.
-struct ConvPre { f32x4 wf[9][2]; };
+#ifndef SB_WRING
+#define SB_WRING 9
+#endif
+struct ConvPre { f32x4 wf[9][2]; const float* Wr; };
+__device__ __forceinline__ void conv_wtap(ConvPre& pre, int t, int slot, int wg, int tid) {
+    const int ct = wg & 3, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(pre.Wr, 9 * 32 * C * 16);
+#ifdef SB_WKN
+    // the SAME bytes read as the product reads its [krow][N] matrix: row = t * 128 + 16 wave + 4 g + s, columns 32 ct + 2 j, + 1 -> element [s] of
+    // fragment n = the value for column 32 ct + 2 j + n (the column permutation only relabels which weight a lane multiplies: timing experiment)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)((t * 128 + 16 * wave + 4 * g + e) * C + 32 * ct + 2 * j) * 4u, 0, 0);
+        pre.wf[slot][0][e] = __uint_as_float(v[0]);
+        pre.wf[slot][1][e] = __uint_as_float(v[1]);
+    }
+#else
+#pragma unroll
+    for (int n = 0; n < 2; ++n) pre.wf[slot][n] = ld16<false>(rs, (unsigned)(((t * 32 + 4 * wave + g) * C) + 32 * ct + 16 * n + j) * 16u);
+#endif
+}
 __device__ __forceinline__ void conv_pre(ConvPre& pre, const float* Wr, int wg, int tid) {
     const int ct = wg & 3, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const __amdgpu_buffer_rsrc_t rs = rsrc(Wr, 9 * 32 * C * 16);
+    pre.Wr = Wr;
+    (void)ct; (void)wave; (void)j; (void)g; (void)rs;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) pre.wf[t][n] = ld16<false>(rs, (unsigned)(((t * 32 + 4 * wave + g) * C) + 32 * ct + 16 * n + j) * 16u);
+    for (int t = 0; t < SB_WRING; ++t) conv_wtap(pre, t, t, wg, tid);
 }
 template <bool COH>
-__device__ __forceinline__ void conv_main(const ConvPre& pre, const float* src, const double* site_in, const float* gamma, const float* beta, const float* film,
-                                          const float* bias, const float* res, float* out, double* site_out, int wg, int tid, float* lds) {
+__device__ __forceinline__ void conv_main(ConvPre& pre, const float* src, const double* site_in, const float* gamma, const float* beta, const float* film,
+                                          const float* bias, const float* res, float* out, double* site_out, int wg, int tid, float* lds, unsigned long long* cdbg = nullptr) {
+#define CST(k) do { if (cdbg && wg == 0 && tid == 0) cdbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
+    CST(0);
     const int rt = wg >> 2, ct = wg & 3, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int r0 = 32 * rt, p = plane_of(r0), pbase = p == 0 ? 0 : (p == 1 ? PB1 : PB2), hrows = p == 0 ? 32 : 16, y = (r0 - pbase) >> 5;
     float* win = lds;
@@ -187,10 +209,12 @@ __device__ __forceinline__ void conv_main(const ConvPre& pre, const float* src, 
         const bool ok = yy >= 0 && yy < hrows;
         raw[u] = ld16<COH>(srs, ok ? (unsigned)((pbase + yy * 32 + xx) * C + 4 * c4) * 4u : 0xFFFFFFF0u);     // (out of range: zeros)
     }
+    CST(1);
     gn_moments<COH>(site_in, p, false, ms, tid);
     // zero pads of the window: columns 0 and 33 of each of the 3 rows
     if (tid < 6 * 32) *reinterpret_cast<f32x4*>(win + ((tid >> 5) / 2 * 34 + ((tid >> 5) & 1) * 33) * LSTR + 4 * (tid & 31)) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    CST(2);
     {
         const float mean = ms[2 * c4], rstd = ms[2 * c4 + 1];
         const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * c4), bt = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
@@ -210,6 +234,7 @@ __device__ __forceinline__ void conv_main(const ConvPre& pre, const float* src, 
         }
     }
     __syncthreads();
+    CST(3);
     f32x4 acc[2][2] = {};
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -222,7 +247,8 @@ __device__ __forceinline__ void conv_main(const ConvPre& pre, const float* src, 
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], pre.wf[t][n][s], acc[m][n], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], pre.wf[t % SB_WRING][n][s], acc[m][n], 0, 0, 0);
+        if (SB_WRING < 9 && t + SB_WRING < 9) conv_wtap(pre, t + SB_WRING, t % SB_WRING, wg, tid);      // (experiment: refill the slot just used)
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -230,8 +256,12 @@ __device__ __forceinline__ void conv_main(const ConvPre& pre, const float* src, 
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[(wave * 32 + 16 * m + 4 * g + r) * 32 + 16 * n + j] = acc[m][n][r];
+    CST(4);
     __syncthreads();
+    CST(5);
     tile_epilogue<COH>(red, 8, bias, res, out, site_out, r0, 32 * ct, wg, tid, dsum);
+    CST(6);
+#undef CST
 }
 
 // -------------------------------------------------------------------------------------------------------------------- qkv phase (1x1, GroupNorm prologue)
@@ -489,7 +519,7 @@ __global__ __launch_bounds__(NTH) void k_p_conv(StageW w, StageBufs b, int which
     CSTAMP(which ? 1 : 0, 0);
     ConvPre pre;
     conv_pre(pre, which ? w.w2 : w.w1, wg, tid);
-    if (!which) conv_main<false>(pre, b.x, b.stats + 0 * STAT_COPIES * STAT_DOUBLES, w.gn1_g, w.gn1_b, nullptr, w.bias1, nullptr, b.h1, b.stats + 1 * STAT_COPIES * STAT_DOUBLES, wg, tid, lds);
+    if (!which) conv_main<false>(pre, b.x, b.stats + 0 * STAT_COPIES * STAT_DOUBLES, w.gn1_g, w.gn1_b, nullptr, w.bias1, nullptr, b.h1, b.stats + 1 * STAT_COPIES * STAT_DOUBLES, wg, tid, lds, b.dbg ? b.dbg + 64 : nullptr);
     else conv_main<false>(pre, b.h1, b.stats + 1 * STAT_COPIES * STAT_DOUBLES, w.gn2_g, w.gn2_b, w.film, w.bias2, b.x, b.h2, b.stats + 2 * STAT_COPIES * STAT_DOUBLES, wg, tid, lds);
     CSTAMP(which ? 1 : 0, 1);
 }
@@ -913,5 +943,12 @@ int main(int argc, char** argv) {
     const char* pn[8] = {"conv1", "conv2", "qkv", "attn2d", "proj", "qkv1d", "attn1d", "proj1d"};
     printf("chain form, workgroup 0 of each launch, cycles from entry to exit (stage 0 of the last chain replay):\n");
     for (int ph = 0; ph < 8; ++ph) printf("  %-8s %8llu   (persistent body: %llu)\n", pn[ph], st[33 + 2 * ph] - st[32 + 2 * ph], st[2 * ph + 1] - st[2 * ph]);
+    {
+        unsigned long long cs[8];
+        CK(hipMemcpy(cs, r.dbg + 64, sizeof cs, hipMemcpyDeviceToHost));
+        printf("conv1 of the chain form, wave 0 of workgroup 0 (cycles): requests issued %llu | statistics in + barrier %llu | window transformed + parked %llu | "
+               "144 MFMAs per wave, 2 waves per SIMD (ideal 9216) %llu | partials stored %llu | reduction + epilogue + statistics %llu\n",
+               cs[1] - cs[0], cs[2] - cs[1], cs[3] - cs[2], cs[4] - cs[3], cs[5] - cs[4], cs[6] - cs[5]);
+    }
     return 0;
 }
