@@ -1224,7 +1224,6 @@ ConvTile conv_pick_tile(int B, int Lout, int N, int nchunks, int Cmain, bool has
 }
 
 size_t conv_smem_bytes(const ConvArgs& a, ConvTile t) {
-    if (t.NW == 112) return conv_rows_smem_bytes(a, t);
     if (t.NW == 80) return conv_win_smem_bytes(a, t);
     if (t.NW == 96) return conv_pw_smem_bytes(a, t);
     if (t.NW == 64) return lin_smem_bytes(a);
@@ -1323,11 +1322,6 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
         a.xmap = 0;            // no padding blocks: every block of the grid takes part in the step hand-over
     }
     hipError_t e = hipErrorInvalidValue;
-    if (t.NW == 112) {           // row-tile 3x3 kernel of the large levels (deep.hip: k_conv_rows); not eligible: the window-staged one, then k_conv
-        if (conv_rows_eligible(a, t.MT, t.NT)) return launch_conv_rows(a, t, s);
-        t.NW = 80;
-        t.NT = t.NT == 4 && t.MT == 2 ? 2 : t.NT;
-    }
     if (t.NW == 80) {            // window-staged 3x3 kernel of the large levels (deep.hip: k_conv_win)
         if (conv_win_eligible(a, t.MT, t.NT)) return launch_conv_win(a, t, s);
         t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);   // (statistics targets are

@@ -1490,275 +1490,6 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
 }
 
 // =====================================================================================
-// k_conv_rows (round 6): the 3x3 conv of a LARGE level for tiles that are whole pieces of image rows
-// =====================================================================================
-// Same ConvArgs, same results layout and statistics hand-over as k_conv_win; what changes is the window and the K loop.  A row tile of
-// TT = 16 MT tokens is either a piece of ONE image row (TT <= r, r % TT == 0) or TT / r whole rows (TT % r == 0); its 3x3 halo is then a
-// rectangle of WR x WC image positions (WR = 3 | TT / r + 2 rows, WC = min(TT, r) + 2 columns), staged in LDS WITH its zero border:
-// position (wy, wx) = image (y0 - 1 + wy, x0 - 1 + wx), zeros outside the plane.  The A fragment of tap (ky, kx) for the lane's output
-// token is then `base + ((ky WC + kx) SW + 16 chunk)`: one scalar offset, no row table, no lane-dependent redirect to a zero row -- the
-// form tools/ubench/stage_bench.hip's conv runs at 92 % of its MFMA time with (k_conv_win's table-driven loop measured 63-70 %).
-// Wave w multiplies the channel chunks w, w + 8, ... of EVERY tap (K order: tap-major per wave), partials summed in wave order.
-// ConvTile{MT, NT, NW = 112, KS = 1, XM = 0}.  Stage A (this round): one or two concatenated sources on the output's own level, no fused
-// skip conv; everything else (upsampled sources, skip rows) stays on k_conv_win / k_conv.
-template <int MT, int NT>
-__global__ __launch_bounds__(DEEP_NTH) void k_conv_rows(const ConvArgs a) {
-    touch_kernargs<(int)sizeof(ConvArgs)>();
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ROWS = 16 * MT, COLS = 16 * NT;
-    constexpr int D = NT == 4 ? 4 : 6;                     // weight chunks in flight per wave (a ring, refilled one chunk per step)
-    constexpr int MAXR = 14;                               // window quads in flight per thread (first batch)
-    typedef float bvec __attribute__((ext_vector_type(NT)));
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = deep_usgpr(tid >> 6);
-    const int i = lane & 15, q = lane >> 4;
-    DEEP_STAMP(0);
-    const int blk = deep_usgpr((int)blockIdx.x);
-    const int ct = deep_usgpr(FDiv{a.inv_Bt}(blk, a.Bt));
-    const int brt = blk - ct * a.Bt;
-    const int b = deep_usgpr(FDiv{a.inv_tiles_per_b}(brt, a.tiles_per_b));
-    const int tok0 = (brt - b * a.tiles_per_b) * ROWS, n0 = ct * COLS;
-    const int Cmain = a.Cmain, SW = Cmain + DEEP_PAD;
-    const int r = a.geo_r, t = a.geo_t, pb1 = r * r, pb2 = pb1 + t * r;
-    const int pl = tok0 >= pb2 ? 2 : (tok0 >= pb1 ? 1 : 0), pbase = pl == 0 ? 0 : (pl == 1 ? pb1 : pb2), hrows = pl == 0 ? r : t;
-    const int y0 = deep_usgpr(FDiv{a.geo_inv_r}(tok0 - pbase, r)), x0 = tok0 - pbase - y0 * r;
-    const int WC = a.cps_q, WR = a.cps_r, NPOS = WC * WR;          // (host: conv_rows_launch_t)
-    DEEP_STAMP(1);
-    float* const lwin = smem;                              // [NPOS][SW]
-    float2* const s_mr = reinterpret_cast<float2*>(lwin + NPOS * SW);                  // [3][32] (mean, rstd)
-    const bool do_gn = a.gn.sums != nullptr;
-    // ---- requests, oldest first: input statistics, GroupNorm vectors of this thread's channel quad, the first D weight chunks, the window (raw)
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
-    f64x2 vraw[STAT_COPIES];
-    if (do_gn && tid < 96) {
-#pragma unroll
-        for (int k = 0; k < STAT_COPIES; ++k) vraw[k] = *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)tid * 2);
-    }
-    const int QW = Cmain >> 2, RP = DEEP_NTH / QW;         // staging map: thread -> quad column qd of positions pr, pr + RP, ...
-    const int qd = tid % QW, pr = tid / QW;
-    const bool stager = pr < RP;
-    const int c4 = 4 * qd, C0 = a.C[0];
-    const float* film = (do_gn && a.gn.film) ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
-    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f}, f1 = be, f2 = be;
-    if (do_gn && stager) {
-        ga = *reinterpret_cast<const f32x4*>(a.gn.gamma + c4);
-        be = *reinterpret_cast<const f32x4*>(a.gn.beta + c4);
-        if (film) { f1 = *reinterpret_cast<const f32x4*>(film + c4); f2 = *reinterpret_cast<const f32x4*>(film + Cmain + c4); }
-    }
-    // weights: wave w owns chunks w + 8 cw (cw < cpw) of every tap; lane (j, q) loads W[krow + 4q + s][n0 + NT j ..] for s = 0 .. 3
-    const int cpw = a.cpt >> 3, n_it = 9 * cpw;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, 9 * Cmain * a.ldw * 4, 0x00020000);
-    const int wlane = ((4 * q) * a.ldw + n0 + NT * i) * 4;
-    const int wstep = 128 * a.ldw * 4;                     // bytes between consecutive chunks of a wave (8 chunks = 128 channel rows)
-    bvec bq[D][4];
-    int w_tap = 0, w_cw = 0, w_off = deep_usgpr(wave * 16 * a.ldw * 4);
-    auto wnext = [&](bvec (&dst)[4]) {                     // (the calls come in K order; past the last chunk: out of range = zeros)
-        const int soff = w_tap < 9 ? w_off : 0x7F000000;
-#pragma unroll
-        for (int sI = 0; sI < 4; ++sI) {
-            if constexpr (NT == 4) dst[sI] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + sI * a.ldw * 4, soff, 0));
-            else dst[sI] = __builtin_bit_cast(bvec, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, wlane + sI * a.ldw * 4, soff, 0));
-        }
-        ++w_cw;
-        w_off += wstep;
-        if (w_cw == cpw) { w_cw = 0; ++w_tap; w_off = (w_tap * Cmain + wave * 16) * a.ldw * 4; }
-    };
-#pragma unroll
-    for (int dI = 0; dI < D; ++dI) wnext(bq[dI]);
-    // window positions of this thread: pos = pr + u RP -> (wy, wx) -> image (y0 - 1 + wy, x0 - 1 + wx); outside the plane: zeros
-    const float inv_wc = 1.0f / (float)WC;
-    auto pos_src = [&](int pos, bool& ok) -> const float* {
-        const int wy = FDiv{inv_wc}(pos, WC), wx = pos - wy * WC;
-        const int Y = y0 - 1 + wy, X = x0 - 1 + wx;
-        ok = pos < NPOS && Y >= 0 && Y < hrows && X >= 0 && X < r;
-        const size_t tok = (size_t)b * a.Lsrc + (ok ? pbase + Y * r + X : 0);
-        return c4 < C0 ? a.src[0] + tok * C0 + c4 : a.src[1] + tok * a.C[1] + (c4 - C0);
-    };
-    const int npass = (NPOS + RP - 1) / RP;
-    f32x4 xr[MAXR];
-    if (stager) {
-#pragma unroll
-        for (int u = 0; u < MAXR; ++u) {
-            if (u >= npass) break;                                     // (uniform)
-            bool ok;
-            const float* p = pos_src(pr + u * RP, ok);                 // (outside the plane: token 0 is read and dropped at the park -- an unconditional load:
-            xr[u] = *reinterpret_cast<const f32x4*>(p);               // a conditional one puts a register copy, i.e. a wait, at its join)
-        }
-    }
-    DEEP_STAMP(2);
-    if (do_gn && tid < 96) {                                           // input statistics: the 8 copies added up -> (mean, rstd) of this (plane, group)
-        f64x2 v0 = vraw[0];
-#pragma unroll
-        for (int k = 1; k < STAT_COPIES; ++k) v0 += vraw[k];
-        const int sg = tid >> 5;
-        const double i0 = a.gn.inv_n[0], i1 = a.gn.inv_n[1], i2 = a.gn.inv_n[2];
-        const double inv_n = sg == 0 ? i0 : (sg == 1 ? i1 : i2);
-        const double mean = v0[0] * inv_n;
-        double var = v0[1] * inv_n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        s_mr[tid] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
-    }
-    __syncthreads();
-    DEEP_STAMP(3);
-    DEEP_STAMP(4);
-    // ---- transform ONCE (the tile lies in one plane: one coefficient set per thread) and park
-    if (stager) {
-        f32x4 A = {1.f, 1.f, 1.f, 1.f}, Bc = {0.f, 0.f, 0.f, 0.f};
-        if (do_gn) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float2 mr = s_mr[pl * 32 + FDiv{a.gn.inv_gs}(c4 + k, a.gn.gs)];
-                const float sc = mr.y * ga[k];
-                const float bi = be[k] - sc * mr.x;
-                const float s1 = film ? 1.0f + f1[k] : 1.0f, sh = film ? f2[k] : 0.f;
-                A[k] = sc * s1;
-                Bc[k] = fmaf(bi, s1, sh);
-            }
-        }
-        const bool act = a.gn.act != 0;
-        auto park = [&](int pos, f32x4 y, bool ok) {
-            if (do_gn) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float tt = fmaf(y[k], A[k], Bc[k]);
-                    y[k] = act ? deep_silu(tt) : tt;
-                }
-            }
-            if (!ok) y = f32x4{0.f, 0.f, 0.f, 0.f};                    // zero padding AFTER the transform (F.conv2d pads the activated tensor)
-            *reinterpret_cast<f32x4*>(lwin + pos * SW + c4) = y;
-        };
-#pragma unroll
-        for (int u = 0; u < MAXR; ++u) {
-            if (u >= npass) break;
-            const int pos = pr + u * RP;
-            bool ok;
-            (void)pos_src(pos, ok);
-            if (pos < NPOS) park(pos, xr[u], ok);
-        }
-        for (int u = MAXR; u < npass; ++u) {                           // (windows of more than MAXR passes: requested late)
-            const int pos = pr + u * RP;
-            bool ok;
-            const float* p = pos_src(pos, ok);
-            if (pos < NPOS) park(pos, ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f}, ok);
-        }
-    }
-    __syncthreads();
-    DEEP_STAMP(5);
-    // ---- K loop
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-        // lane (i, q): output token 16 mt + i of the tile -> window position (ty + 1, x + 1) for the centre tap
-        const float* abase[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int tl = 16 * mt + i;
-            const int ty = ROWS > r ? FDiv{a.geo_inv_r}(tl, r) : 0, tx = tl - ty * r;
-            abase[mt] = lwin + (ty * WC + tx) * SW + 16 * wave + 4 * q;
-        }
-        int a_tap = 0, a_cw = 0, a_off = 0;                // float offset of (tap, cw): (ky WC + kx) SW + 128 cw
-        auto anext = [&](f32x4 (&av)[MT]) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(abase[mt] + a_off);
-            const bool last = a_tap == 8 && a_cw == cpw - 1;           // past the wave's last chunk: stay (those weights are zeros)
-            if (!last) {
-                ++a_cw;
-                a_off += 128;
-                if (a_cw == cpw) {
-                    a_cw = 0;
-                    ++a_tap;
-                    const int ky = a_tap >= 6 ? 2 : (a_tap >= 3 ? 1 : 0), kx = a_tap - 3 * ky;
-                    a_off = (ky * WC + kx) * SW;
-                }
-            }
-        };
-        auto mma = [&](const f32x4 (&av)[MT], const bvec (&w)[4]) {
-#pragma unroll
-            for (int sI = 0; sI < 4; ++sI)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nb = 0; nb < NT; ++nb) acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][sI], w[sI][nb], acc[mt][nb], 0, 0, 0);
-        };
-        f32x4 avA[MT], avB[MT];
-        anext(avA);
-        int it = 0;
-        for (; it + D <= n_it; it += D) {
-#pragma unroll
-            for (int dI = 0; dI < D; ++dI) {
-                if (dI & 1) { anext(avA); mma(avB, bq[dI]); }
-                else { anext(avB); mma(avA, bq[dI]); }
-                wnext(bq[dI]);
-            }
-        }
-        const int rem = n_it - it;
-#pragma unroll
-        for (int dI = 0; dI < D; ++dI)
-            if (dI < rem) {
-                if (dI & 1) { anext(avA); mma(avB, bq[dI]); }
-                else { anext(avB); mma(avA, bq[dI]); }
-            }
-    }
-    DEEP_STAMP(6);
-    // ---- epilogue operands of this thread's output quad, requested before the partial tiles are exchanged
-    constexpr int QPR = COLS / 4;
-    static_assert(ROWS * QPR <= DEEP_NTH, "one output quad per thread");
-    const int e_rr = tid / QPR, e_cq = tid - e_rr * QPR;
-    const int e_tok = tok0 + e_rr, e_n = n0 + 4 * e_cq;
-    const bool e_on = tid < ROWS * QPR && e_tok < a.Lout;
-    f32x4 e_add = {0.f, 0.f, 0.f, 0.f}, e_bb = e_add, e_res = e_add;
-    if (e_on) {
-        e_add = *reinterpret_cast<const f32x4*>(a.bias + e_n);
-        if (a.bias_b) e_bb = *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + e_n);
-        if (a.res) e_res = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + e_tok) * a.N + e_n);
-    }
-    __syncthreads();
-    constexpr int LDR = COLS + 4;
-    float* const red = smem;
-    {
-        float* my = red + (size_t)wave * ROWS * LDR + (4 * q) * LDR + NT * i;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                bvec tv;
-#pragma unroll
-                for (int nb = 0; nb < NT; ++nb) tv[nb] = acc[mt][nb][rr];
-                *reinterpret_cast<bvec*>(my + (16 * mt + rr) * LDR) = tv;
-            }
-    }
-    __syncthreads();
-    DEEP_STAMP(7);
-    float* scratch = red + 8 * ROWS * LDR;
-    {
-        double* st = reinterpret_cast<double*>(scratch + 4);
-        for (int e = tid; e < a.nstat * 96 * 2; e += DEEP_NTH) st[e] = 0.0;
-        if (a.nstat) __syncthreads();
-    }
-    if (e_on) {
-        const float* rp = red + e_rr * LDR + 4 * e_cq;
-        f32x4 v = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-        for (int w = 1; w < 8; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
-        v += e_add;
-        if (a.bias_b) v += e_bb;
-        if (a.res) v += e_res;
-        *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + e_tok) * a.N + e_n) = v;
-        if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, e_tok, e_n, v);
-        if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, e_tok, e_n, v);
-    }
-    if (a.nstat) {
-        __syncthreads();
-        deep_stat_flush_one(a.stat[0], 0, a.stat_cstride, scratch, b, tid);
-        if (a.nstat > 1) deep_stat_flush_one(a.stat[1], 1, a.stat_cstride, scratch, b, tid);
-    }
-    DEEP_STAMP(9);
-}
-
-// =====================================================================================
 // k_conv_pw: 1x1 conv on identity rows at the LARGE levels (qkv / proj_out of the attention blocks at 512 / 2048 tokens)
 // =====================================================================================
 // Same arguments, results layout and statistics hand-over as k_conv (ConvArgs).  k_conv runs a 1x1 conv as a one-tap convolution with
@@ -2229,9 +1960,7 @@ hipError_t deep_init_attrs() {
                         reinterpret_cast<const void*>(&k_conv_pw<2, 1, 8>), reinterpret_cast<const void*>(&k_conv_pw<2, 2, 8>),
                         reinterpret_cast<const void*>(&k_conv_pw<1, 1, 6>), reinterpret_cast<const void*>(&k_conv_pw<2, 1, 6>),
                         reinterpret_cast<const void*>(&k_conv_pw<1, 1, 4>), reinterpret_cast<const void*>(&k_conv_pw<2, 1, 4>),
-                        reinterpret_cast<const void*>(&k_conv_pw<1, 1, 2>), reinterpret_cast<const void*>(&k_conv_pw<2, 1, 2>),
-                        reinterpret_cast<const void*>(&k_conv_rows<1, 2>), reinterpret_cast<const void*>(&k_conv_rows<1, 4>),
-                        reinterpret_cast<const void*>(&k_conv_rows<2, 2>), reinterpret_cast<const void*>(&k_conv_rows<2, 4>)};
+                        reinterpret_cast<const void*>(&k_conv_pw<1, 1, 2>), reinterpret_cast<const void*>(&k_conv_pw<2, 1, 2>)};
     for (const void* f : fa) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -2445,65 +2174,6 @@ hipError_t launch_conv_pw(const ConvArgs& a, ConvTile t, hipStream_t s) {
     if (t.MT == 2 && t.NT == 1 && nwa == 4) return conv_pw_launch_t<2, 1, 4>(a, s);
     if (t.MT == 1 && t.NT == 1 && nwa == 2) return conv_pw_launch_t<1, 1, 2>(a, s);
     if (t.MT == 2 && t.NT == 1 && nwa == 2) return conv_pw_launch_t<2, 1, 2>(a, s);
-    return hipErrorInvalidValue;
-}
-
-// ---- k_conv_rows (ConvTile{MT, NT, NW = 112, KS = 1, XM = 0}) ----
-static bool conv_rows_window(const ConvArgs& a, int MT, int* wr, int* wc) {
-    const int TT = 16 * MT, r = a.geo_r, t = a.geo_t;
-    if (r < 1 || t < 1) return false;
-    if (TT <= r) { if (r % TT) return false; *wr = 3; *wc = TT + 2; }
-    else { if (TT % r || (t * r) % TT) return false; *wr = TT / r + 2; *wc = r + 2; }
-    return (r * r) % TT == 0 && (t * r) % TT == 0;          // tiles never straddle planes
-}
-static size_t conv_rows_layout(const ConvArgs& a, int MT, int NT) {
-    int wr = 0, wc = 0;
-    if (!conv_rows_window(a, MT, &wr, &wc)) return (size_t)1 << 30;
-    const size_t fl = (size_t)wr * wc * (a.Cmain + DEEP_PAD) + 192 + 64;
-    const size_t red = (size_t)8 * 16 * MT * (16 * NT + 4) + DEEP_FIN_FLOATS;
-    return (fl > red ? fl : red) * 4 + 64;
-}
-bool conv_rows_eligible(const ConvArgs& a, int MT, int NT) {
-    if (!((MT == 1 || MT == 2) && (NT == 2 || NT == 4))) return false;
-    if (a.ntaps != 9 || a.geo_main != 1 || a.nmain < 1 || a.nmain > 2 || a.nskip != 0 || a.Cskip != 0 || a.geo_skip) return false;
-    if (a.out_cm || a.ddim || a.bias2 || a.gn.whole) return false;
-    if ((a.Cmain & 127) || a.Cmain > 768 || a.N % (16 * NT) || a.Lsrc != a.Lout || (a.res && a.Lskip != a.Lout)) return false;
-    if (a.nmain == 2 && ((a.C[0] & 3) || a.C[0] + a.C[1] != a.Cmain)) return false;
-    if (a.nmain == 1 && a.C[0] != a.Cmain) return false;
-    if (a.Lout != a.geo_r * a.geo_r + 2 * a.geo_t * a.geo_r) return false;
-    if (512 / (a.Cmain >> 2) < 1) return false;
-    for (int t = 0; t < a.nstat; ++t)
-        if (a.stat[t].coff & 3) return false;
-    return conv_rows_layout(a, MT, NT) <= 160 * 1024;
-}
-size_t conv_rows_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_rows_layout(a, t.MT, t.NT); }
-template <int MT, int NT>
-static hipError_t conv_rows_launch_t(const ConvArgs& a0, hipStream_t s) {
-    ConvArgs a = a0;
-    if (!conv_rows_eligible(a, MT, NT)) return hipErrorInvalidValue;
-    int wr = 0, wc = 0;
-    conv_rows_window(a, MT, &wr, &wc);
-    const int tiles = a.Lout / (16 * MT), groups = a.N / (16 * NT);
-    a.KS = 1;
-    a.xmap = 0;
-    a.cps_q = wc;
-    a.cps_r = wr;
-    a.cpt = a.Cmain / 16;
-    a.tiles_per_b = tiles;
-    a.tiles_n = groups;
-    a.Bt = a.B * tiles;
-    a.inv_tiles_per_b = 1.0f / (float)tiles;
-    a.inv_Bt = 1.0f / (float)a.Bt;
-    a.geo_inv_r = 1.0f / (float)a.geo_r;
-    if ((long)a.Bt * groups >= (1L << 21)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_conv_rows<MT, NT>), dim3((unsigned)(a.Bt * groups)), dim3(DEEP_NTH), conv_rows_layout(a, MT, NT), s, a);
-    return hipGetLastError();
-}
-hipError_t launch_conv_rows(const ConvArgs& a, ConvTile t, hipStream_t s) {
-    if (t.MT == 1 && t.NT == 2) return conv_rows_launch_t<1, 2>(a, s);
-    if (t.MT == 1 && t.NT == 4) return conv_rows_launch_t<1, 4>(a, s);
-    if (t.MT == 2 && t.NT == 2) return conv_rows_launch_t<2, 2>(a, s);
-    if (t.MT == 2 && t.NT == 4) return conv_rows_launch_t<2, 4>(a, s);
     return hipErrorInvalidValue;
 }
 

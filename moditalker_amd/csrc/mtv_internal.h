@@ -446,10 +446,6 @@ bool conv_win_eligible(const ConvArgs& a, int MT, int NT);
 int conv_win_selftest(int r, int t, bool up, int Lout, int Lsrc);      // host-only check of the window arithmetic (0 = ok)
 size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s);
-// k_conv_rows<MT, NT> (deep.hip, round 6): 3x3 conv of the large levels, tiles = pieces of image rows, padded 2-D window, arithmetic A addresses -- ConvTile NW == 112
-bool conv_rows_eligible(const ConvArgs& a, int MT, int NT);
-size_t conv_rows_smem_bytes(const ConvArgs& a, ConvTile t);
-hipError_t launch_conv_rows(const ConvArgs& a, ConvTile t, hipStream_t s);
 // k_conv_pw<MT, NTW> (deep.hip): 1x1 conv on identity rows, rows normalised once into LDS, waves side by side along N (ConvTile NW = 96)
 bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW, int wcode = 1);     // wcode = ConvTile::KS of the tile: 1 = all 8 waves multiply, 6 / 4 / 2 = that many (column tile 16 NTW x waves)
 size_t conv_pw_smem_bytes(const ConvArgs& a, ConvTile t);

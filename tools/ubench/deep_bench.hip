@@ -701,8 +701,7 @@ static void do_win(int nops, int r, int t, int C) {
     std::vector<float> ref;
     auto run_tile = [&](ConvTile tile) {
         if (tile.NW == 80 && !conv_win_eligible(ca[0], tile.MT, tile.NT)) return;
-        if (tile.NW == 112 && !conv_rows_eligible(ca[0], tile.MT, tile.NT)) return;
-        if (tile.NW != 80 && tile.NW != 112 && conv_smem_bytes(ca[0], tile) > 120 * 1024) return;
+        if (tile.NW != 80 && conv_smem_bytes(ca[0], tile) > 120 * 1024) return;
         CK(hipMemcpy(actA[0], x.data(), x.size() * 4, hipMemcpyHostToDevice));
         hipGraph_t gr; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -726,7 +725,7 @@ static void do_win(int nops, int r, int t, int C) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("  tile %d,%d,%d,%d,%d  %7.2f us per op   (max|diff| to the first tile after %d ops %.2e)\n", tile.MT, tile.NT, tile.NW, tile.KS, tile.XM, ms * 1e3 / reps / nops, nops, worst);
 #ifdef MTV_DEEP_STAMP
-        if (tile.NW == 80 || tile.NW == 112) {
+        if (tile.NW == 80) {
             unsigned long long h[64];
             CK(hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
             static const char* nm[10] = {"entry", "decoded", "requests issued", "tables+barrier", "stats barrier", "window parked", "mfma done", "partials parked", "-", "end"};
@@ -742,8 +741,7 @@ static void do_win(int nops, int r, int t, int C) {
         CK(hipGraphExecDestroy(ge));
         CK(hipGraphDestroy(gr));
     };
-    const ConvTile tiles[] = {{1, 4, 8, 1, 0}, {2, 4, 8, 1, 0}, {2, 2, 8, 1, 0}, {2, 4, 4, 1, 0}, {1, 2, 8, 1, 0}, {1, 4, 80, 1, 0}, {1, 2, 80, 1, 0}, {2, 2, 80, 1, 0}, {1, 2, 80, 1, 1}, {2, 2, 80, 1, 1},
-                              {1, 2, 112, 1, 0}, {1, 4, 112, 1, 0}, {2, 2, 112, 1, 0}, {2, 4, 112, 1, 0}};
+    const ConvTile tiles[] = {{1, 4, 8, 1, 0}, {2, 4, 8, 1, 0}, {2, 2, 8, 1, 0}, {2, 4, 4, 1, 0}, {1, 2, 8, 1, 0}, {1, 4, 80, 1, 0}, {1, 2, 80, 1, 0}, {2, 2, 80, 1, 0}, {1, 2, 80, 1, 1}, {2, 2, 80, 1, 1}};
     for (const ConvTile& tl : tiles) run_tile(tl);
 }
 
