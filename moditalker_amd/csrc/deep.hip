@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     touch_kernargs<(int)sizeof(ConvArgs)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, COLS = 16 * NT;
-    constexpr int G = MT * NT <= 2 ? 5 : 3;                // weight chunks per register set (two sets: 2 G chunks of look-ahead per wave)
+    constexpr int G = MT * NT <= 2 ? 5 : (MT * NT == 8 ? 2 : 3);       // weight chunks per register set (two sets: 2 G chunks of look-ahead per wave; 2 x 4: 64 of its registers)
     constexpr int MAXR = 12;                               // window rows in flight per thread (first pass)
     static_assert(MAXR >= 2 * G, "the first 2 G weight chunks are requested between the rows of the first pass");
     typedef float bvec __attribute__((ext_vector_type(NT)));
@@ -1955,7 +1955,7 @@ hipError_t deep_init_attrs() {
     }
     const void* fa[] = {reinterpret_cast<const void*>(&k_deep_attn<16>), reinterpret_cast<const void*>(&k_deep_attn<32>), reinterpret_cast<const void*>(&k_deep_attn<64>),
                         reinterpret_cast<const void*>(&k_conv_win<1, 4>), reinterpret_cast<const void*>(&k_conv_win<1, 2>),
-                        reinterpret_cast<const void*>(&k_conv_win<2, 2>),
+                        reinterpret_cast<const void*>(&k_conv_win<2, 2>), reinterpret_cast<const void*>(&k_conv_win<2, 4>),
                         reinterpret_cast<const void*>(&k_conv_pw<1, 1, 8>), reinterpret_cast<const void*>(&k_conv_pw<1, 2, 8>),
                         reinterpret_cast<const void*>(&k_conv_pw<2, 1, 8>), reinterpret_cast<const void*>(&k_conv_pw<2, 2, 8>),
                         reinterpret_cast<const void*>(&k_conv_pw<1, 1, 6>), reinterpret_cast<const void*>(&k_conv_pw<2, 1, 6>),
@@ -2068,7 +2068,7 @@ int conv_win_selftest(int r, int t, bool up, int Lout, int Lsrc) {
 }
 
 bool conv_win_eligible(const ConvArgs& a, int MT, int NT) {
-    if (!((MT == 1 && (NT == 2 || NT == 4)) || (MT == 2 && NT == 2))) return false;       // (2 x 4 spills at 512 threads)
+    if (!((MT == 1 && (NT == 2 || NT == 4)) || (MT == 2 && (NT == 2 || NT == 4)))) return false;       // (2 x 4: round 6, with a 2 x 2-chunk weight ring)
     if (a.ntaps != 9 || (a.geo_main != 1 && a.geo_main != 2) || a.out_cm || a.ddim || a.N % (16 * NT) || (a.Cmain & 15) || (a.Cskip & 15) || a.Cmain > 2048) return false;
     if (a.nmain == 2 && (a.C[0] & 3)) return false;
     if (a.nskip == 2 && (a.C[2] & 3)) return false;
@@ -2119,6 +2119,7 @@ hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s) {
     if (t.MT == 1 && t.NT == 4) return conv_win_launch_t<1, 4>(a, t.XM, s);
     if (t.MT == 1 && t.NT == 2) return conv_win_launch_t<1, 2>(a, t.XM, s);
     if (t.MT == 2 && t.NT == 2) return conv_win_launch_t<2, 2>(a, t.XM, s);
+    if (t.MT == 2 && t.NT == 4) return conv_win_launch_t<2, 4>(a, t.XM, s);
     return hipErrorInvalidValue;
 }
 

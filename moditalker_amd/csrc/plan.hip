@@ -1421,7 +1421,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             }
             // the window-staged 3x3 kernel (deep.hip, k_conv_win): GroupNorm / FiLM / SiLU once per element, all taps from LDS
             if (a.ntaps == 9 && (long)a.B * a.Lout >= 256) {
-                static const int tw[][2] = {{1, 4}, {1, 2}, {2, 2}};
+                static const int tw[][2] = {{1, 4}, {1, 2}, {2, 2}, {2, 4}};
                 // block order by rule, not by timing (it moves L2 misses, not time: profiles/r04_conv_win_xcd_order.txt): one XCD per
                 // weight column tile where the weights are the larger operand
                 const int XM = wbytes >= abytes ? 1 : 0;
@@ -2348,7 +2348,7 @@ int mtv_debug_force_pw_waves(int mt, int ntw, int waves) {
 
 int mtv_debug_force_win(int mt, int nt) {
     if (mt == 0) { g_force_win[0] = 0; return MTV_OK; }
-    if (!((mt == 1 && (nt == 2 || nt == 4)) || (mt == 2 && nt == 2))) return fail(MTV_ERR_INVALID, "k_conv_win tile must be 1x2, 1x4 or 2x2");
+    if (!((mt == 1 || mt == 2) && (nt == 2 || nt == 4))) return fail(MTV_ERR_INVALID, "k_conv_win tile must be 1x2, 1x4, 2x2 or 2x4");
     g_force_win[0] = mt; g_force_win[1] = nt;
     return MTV_OK;
 }

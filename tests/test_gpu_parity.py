@@ -567,7 +567,7 @@ def test_deep_kernels_against_cpu_conv_and_attention():
         assert out.returncode == 0 and ok in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 
 
-@pytest.mark.parametrize("mt,nt", [(1, 4), (1, 2), (2, 2)])
+@pytest.mark.parametrize("mt,nt", [(1, 4), (1, 2), (2, 2), (2, 4)])
 def test_window_staged_conv_kernel_vs_reference_golden(mt, nt):
     """k_conv_win (csrc/deep.hip: the transformed input window of a row tile staged in LDS once, all nine taps read from it) forced
     onto every eligible 3x3 conv: eps of the base UNet vs the reference golden and a ragged two-clip geometry (row tiles that straddle

@@ -741,7 +741,7 @@ static void do_win(int nops, int r, int t, int C) {
         CK(hipGraphExecDestroy(ge));
         CK(hipGraphDestroy(gr));
     };
-    const ConvTile tiles[] = {{1, 4, 8, 1, 0}, {2, 4, 8, 1, 0}, {2, 2, 8, 1, 0}, {2, 4, 4, 1, 0}, {1, 2, 8, 1, 0}, {1, 4, 80, 1, 0}, {1, 2, 80, 1, 0}, {2, 2, 80, 1, 0}, {1, 2, 80, 1, 1}, {2, 2, 80, 1, 1}};
+    const ConvTile tiles[] = {{1, 4, 8, 1, 0}, {2, 4, 8, 1, 0}, {2, 2, 8, 1, 0}, {2, 4, 4, 1, 0}, {1, 2, 8, 1, 0}, {1, 4, 80, 1, 0}, {1, 2, 80, 1, 0}, {2, 2, 80, 1, 0}, {1, 2, 80, 1, 1}, {2, 2, 80, 1, 1}, {2, 4, 80, 1, 0}};
     for (const ConvTile& tl : tiles) run_tile(tl);
 }
 
