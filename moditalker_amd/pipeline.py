@@ -230,20 +230,32 @@ class MToVSampler:
 
     @torch.no_grad()
     def run_identity(self, chunks: Iterable[Sequence[torch.Tensor]], use_last_as_reference: bool = False,
-                     out_dir: Optional[str] = None, noise_per_chunk: Optional[Sequence] = None, **sample_kw):
+                     out_dir: Optional[str] = None, noise_per_chunk: Optional[Sequence] = None, overlap: bool = False,
+                     num_frames: Optional[int] = None, **sample_kw):
         """The per-identity loop (sample.py:305-432): chunks yield (x_ref, x, x_l, masked_x) in 0..255, [B,T,C,H,W].
         Chunks of one identity are sequential when chained (chunk k+1 needs chunk k's last frame): shard by identity.
         Returns the list of uint8 frame arrays [B, T, H, W, 3]; when out_dir is given writes frames/NNNN.png with the B clips
-        of the batch side by side ([H, B*W, 3] per frame), the reference's grid_size=(k, 1) layout (sample.py:79-104)."""
+        of the batch side by side ([H, B*W, 3] per frame), the reference's grid_size=(k, 1) layout (sample.py:79-104).
+
+        `overlap` (sample_crossID.py:185,343-348, the cross-identity script's `--overlap`): chunks start every T/2 frames instead of
+        every T -- chunk `it` covers frames [it T/2, it T/2 + T), its frame files overwrite the second half of the chunk before, and
+        with `use_last_as_reference` its reference is the last frame of the chunk that ENDED where it starts (the folder
+        `references/<ldmk_srt>` there: chunk it - 2; the first two chunks find none and keep their own x_ref, sample_crossID.py:394-396).
+        `num_frames` (sample_crossID.py:352-353): stop before the first chunk that starts past it."""
         results = []
-        image_cond = None
+        T = self.ae.s
+        stride = T // 2 if overlap else T
+        chained = {}                                  # frame index a chunk ended at -> image_cond made from its last frame
         for it, (x_ref, x, x_l, masked_x) in enumerate(chunks):
-            ldmk_srt, T = it * self.ae.s, self.ae.s
+            ldmk_srt = it * stride
+            if num_frames is not None and num_frames < ldmk_srt:
+                break
             cond = self.conditioning(x_ref, x, x_l, masked_x)
             nz = noise_per_chunk[it] if noise_per_chunk is not None else None
-            z, fake = self.sample_chunk(cond, image_cond=image_cond if use_last_as_reference else None, noise=nz, **sample_kw)
+            z, fake = self.sample_chunk(cond, image_cond=chained.get(ldmk_srt) if use_last_as_reference else None, noise=nz, **sample_kw)
             if use_last_as_reference:
-                image_cond = self.chained_image_cond(fake, out_dir, ldmk_srt + T)
+                chained[ldmk_srt + T] = self.chained_image_cond(fake, out_dir, ldmk_srt + T)
+                chained.pop(ldmk_srt - stride, None)  # (no longer reachable: keeps at most two latents alive)
             u8 = frames_to_uint8(fake)
             results.append(u8)
             if out_dir is not None:

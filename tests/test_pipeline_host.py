@@ -123,6 +123,31 @@ def test_chunk_loop_ordering_and_chaining(tmp_path):
     assert all(abs(float(c["image_cond"].mean()) - 1.0) < 1e-6 for c in dm2.calls) and all(c["noised_start"] is None for c in dm2.calls)
 
 
+def test_overlapping_chunks_of_the_cross_identity_script(tmp_path):
+    """sample_crossID.py:185,343-353 (`--overlap`, `--num_frames`): chunks every 8 frames; chunk `it` is chained to the chunk that ENDED at
+    its first frame (it - 2: `references/<ldmk_srt>`), the first two keep their own x_ref; frame files of the overlapped half are
+    overwritten; the loop stops before the first chunk that starts past num_frames."""
+    ae, dm = _StubAE(), _StubDM()
+    s = P.MToVSampler(dm, ae)
+    mk = lambda v: torch.full((1, 16, 3, 8, 8), float(v))
+    chunks = [(mk(255), mk(10 + i), mk(20), mk(30)) for i in range(5)]
+    out = s.run_identity(chunks, use_last_as_reference=True, out_dir=str(tmp_path), overlap=True, num_frames=24)
+    assert len(out) == 4 and len(dm.calls) == 4                 # chunks start at 0, 8, 16, 24; the fifth would start at 32 > 24
+    assert sorted(os.listdir(tmp_path / "references")) == ["16", "24", "32", "40"]
+    assert len(os.listdir(tmp_path / "frames")) == 24 + 16      # frames 0 .. 39
+    from PIL import Image
+    own = 1.0                                                   # x_ref = 255 -> +1
+    v16 = float(np.asarray(Image.open(tmp_path / "references" / "16" / "0.png")).mean()) / 255 * 2 - 1
+    v24 = float(np.asarray(Image.open(tmp_path / "references" / "24" / "0.png")).mean()) / 255 * 2 - 1
+    got = [float(c["image_cond"].mean()) for c in dm.calls]
+    assert abs(got[0] - own) < 1e-6 and abs(got[1] - own) < 1e-6          # nothing ended at frame 0 or 8
+    assert abs(got[2] - v16) < 1e-6 and abs(got[3] - v24) < 1e-6          # chunk 2 <- chunk 0's last frame, chunk 3 <- chunk 1's
+    # without overlap the same call chains every chunk to its predecessor (stride = T)
+    ae2, dm2 = _StubAE(), _StubDM()
+    P.MToVSampler(dm2, ae2).run_identity(chunks[:3], use_last_as_reference=True, out_dir=str(tmp_path / "plain"))
+    assert sorted(os.listdir(tmp_path / "plain" / "references"), key=int) == ["16", "32", "48"]
+
+
 def test_batched_identity_writes_the_reference_grid_and_ignores_stale_pngs(tmp_path):
     """B = 2 clips per call: frames/NNNN.png holds both clips side by side ([H, 2W, 3], the reference's grid_size=(k, 1),
     sample.py:79-104), and the chained image_cond is read back from exactly the two files just written -- a stale
