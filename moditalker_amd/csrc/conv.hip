@@ -660,17 +660,30 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         }
         if (!a.out_cm && n + 3 < a.N) {
             *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
+        } else if (dd) {
+            // sampler-step head (N == 4 == the sample's channels): v is eps; x <- DDIM update, in the external
+            // layout and as channels 0..3 of the packed input of the next step's stem conv.  The (up to) four x and four
+            // noise values are requested together: one round trip instead of one per channel (the store of channel k
+            // may alias the load of channel k + 1 as far as the compiler knows).
+            float xo[4], nz[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = n + k < a.N;
+                const size_t ix = ((size_t)b * a.N + n + (in ? k : 0)) * a.Lout + tok;
+                xo[k] = ddv.x[ix];
+                nz[k] = stp.noise_index >= 0 ? ddv.noise[(size_t)stp.noise_index * ddv.n_per_draw + ix] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (n + k >= a.N) break;
+                const size_t ix = ((size_t)b * a.N + n + k) * a.Lout + tok;
+                const float xn = ddim_update_elem(stp, xo[k], v[k], nz[k]);
+                ddv.x[ix] = xn;
+                ddv.h0[((size_t)b * a.Lout + tok) * 16 + n + k] = xn;
+            }
         } else {
             for (int k = 0; k < 4 && n + k < a.N; ++k) {
-                if (dd) {
-                    // sampler-step head (N == 4 == the sample's channels): v is eps; x <- DDIM update, in the external
-                    // layout and as channels 0..3 of the packed input of the next step's stem conv
-                    const size_t ix = ((size_t)b * a.N + n + k) * a.Lout + tok;
-                    const float nz = stp.noise_index >= 0 ? ddv.noise[(size_t)stp.noise_index * ddv.n_per_draw + ix] : 0.f;
-                    const float xn = ddim_update_elem(stp, ddv.x[ix], v[k], nz);
-                    ddv.x[ix] = xn;
-                    ddv.h0[((size_t)b * a.Lout + tok) * 16 + n + k] = xn;
-                } else if (a.out_cm) a.out[((size_t)b * a.N + n + k) * a.Lout + tok] = v[k];
+                if (a.out_cm) a.out[((size_t)b * a.N + n + k) * a.Lout + tok] = v[k];
                 else a.out[((size_t)b * a.Lout + tok) * a.N + n + k] = v[k];
             }
         }
