@@ -175,6 +175,9 @@ int mtv_debug_force_lin(int mt, int nt, int nwv);
  * the window-staged kernel k_conv_win<mt, nt> (row tile 16 mt x column tile 16 nt; the transformed input rows of the tile and their
  * halo staged in LDS once, csrc/deep.hip) instead of the tuned choice; mt = 0 switches it off again. */
 int mtv_debug_force_win(int mt, int nt);
+/* ... with ks = 1 | 2 | 4 K slices per tile (round 6: each slice stages its 1 / ks of the input channels; partial tiles meet in the plan's
+ * split-K slab inside the launch) on the convs that can take them -- no fused skip conv, whole 16-channel chunks per slice; the others run unsliced. */
+int mtv_debug_force_win_ks(int mt, int nt, int ks);
 /* Testing aid: plans built after this call run every eligible 1x1 convolution on identity rows (the attention blocks' qkv / proj_out,
  * unet.py:234,253) on k_conv_pw<mt, ntw> (16 mt rows normalised once into LDS, 8 waves side by side along 128 ntw output channels, ntw = 1 | 2,
  * whole K per wave; csrc/deep.hip) instead of the tuned choice; mt = 0 switches it off again. */

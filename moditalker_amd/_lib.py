@@ -101,6 +101,7 @@ SYMBOLS = [
     ("mtv_debug_force_lds", C.c_int, [C.c_int, C.c_int]),
     ("mtv_debug_force_lin", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_force_win", C.c_int, [C.c_int, C.c_int]),
+    ("mtv_debug_force_win_ks", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_force_pw", C.c_int, [C.c_int, C.c_int]),
     ("mtv_debug_force_pw_waves", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("mtv_debug_force_b3", C.c_int, [C.c_int, C.c_int, C.c_int]),

@@ -1336,7 +1336,7 @@ hipError_t launch_conv(const ConvArgs& a0, ConvTile t, hipStream_t s) {
     }
     hipError_t e = hipErrorInvalidValue;
     if (t.NW == 80) {            // window-staged 3x3 kernel of the large levels (deep.hip: k_conv_win)
-        if (conv_win_eligible(a, t.MT, t.NT)) return launch_conv_win(a, t, s);
+        if (conv_win_eligible(a, t.MT, t.NT, t.KS)) return launch_conv_win(a, t, s);
         t = conv_pick_tile(a.B, a.Lout, a.N, a.ntaps * (a.Cmain / 16) + a.Cskip / 16, a.Cmain, a.gn.sums != nullptr);   // (statistics targets are
         t.KS = 1;                                                                                                       // attached after the op is created)
         a.KS = 1;

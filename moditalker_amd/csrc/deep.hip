@@ -1155,7 +1155,17 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     // tile is fetched by ONE L2 (tiles_n a multiple of 8: Sx column tiles per XCD) or by 8 / tiles_n of them (tiles_n = 2^Sx < 8) and
     // the (smaller) activation windows are what the XCDs re-read.  Speed only.
     DEEP_STAMP(0);
-    const int blk = deep_usgpr((int)blockIdx.x);
+    // K slices (ConvTile::KS = 2 / 4, round 6; convs without a fused skip conv): slice z = the z-th 1 / KS of the input channels, all nine
+    // taps -- its window holds only those channels -- and the slices of a tile are Bt x tiles_n workgroups apart (each slice keeps the
+    // block order below).  Partial tiles meet in the slab exactly as k_conv's (write-through stores, one ticket per tile, the last slice
+    // sums them in slice order and runs the epilogue).
+    const int KS = deep_usgpr(a.KS);
+    int blk = deep_usgpr((int)blockIdx.x);
+    int z = 0;
+    if (KS > 1) {
+        z = deep_usgpr(FDiv{a.inv_tiles_n}(blk, a.Bt * a.tiles_n));
+        blk -= z * a.Bt * a.tiles_n;
+    }
     int ct, brt;
     if (a.xmap == 0) {
         ct = FDiv{a.inv_Bt}(blk, a.Bt);
@@ -1174,7 +1184,8 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     const int b = deep_usgpr(FDiv{a.inv_tiles_per_b}(brt, a.tiles_per_b));
     const int tok0 = (brt - b * a.tiles_per_b) * ROWS, n0 = ct * COLS;
     const int Cmain = a.Cmain, Cskip = a.Cskip;
-    const int SW = Cmain + DEEP_PAD, SK = Cskip + DEEP_PAD;
+    const int Cs = a.cps_r, coff = z * Cs;                 // this slice's channels [coff, coff + Cs) (Cs = Cmain without K slices)
+    const int SW = Cs + DEEP_PAD, SK = Cskip + DEEP_PAD;
     DEEP_STAMP(1);
     const int wcap = a.rec_cap;                            // window capacity in rows (host); row wcap of the window = zeros
     float* const lwin = smem;                              // [wcap + 1][SW]
@@ -1194,10 +1205,10 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < STAT_COPIES; ++k) vraw[k] = *reinterpret_cast<const f64x2*>(a.gn.sums + (size_t)k * a.gn.cstride + (size_t)b * 192 + (size_t)tid * 2);
     }
-    const int QW = Cmain >> 2, RP = DEEP_NTH / QW;         // staging map: thread -> quad column qd of rows rl, rl + RP, ...
+    const int QW = Cs >> 2, RP = DEEP_NTH / QW;            // staging map: thread -> quad column qd of rows rl, rl + RP, ...
     const int qd = tid % QW, rl = tid / QW;
     const bool stager = rl < RP;
-    const int c4 = 4 * qd, C0 = a.C[0];
+    const int c4l = 4 * qd, c4 = coff + c4l, C0 = a.C[0];  // c4l: column in the window, c4: channel of the conv's input
     const float* film = (do_gn && a.gn.film) ? a.gn.film + (size_t)b * a.gn.film_stride : nullptr;
     f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = ga, f1 = ga, f2 = ga;
     if (do_gn && stager) {
@@ -1244,7 +1255,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
             // W row of the chunk's first channel: tap-major over the concatenated main channels, then the skip channels (k_conv's
             // order of rows); a chunk past the end reads out of range = zeros
             int krow = 9 * Cmain + (c - nmain_ch) * 16;
-            if (c < nmain_ch) { const int tap = FDiv{a.inv_cpt}(c, cpt); krow = tap * Cmain + (c - tap * cpt) * 16; }
+            if (c < nmain_ch) { const int tap = FDiv{a.inv_cpt}(c, cpt); krow = tap * Cmain + coff + (c - tap * cpt) * 16; }
             const int soff = c < nch ? krow * a.ldw * 4 : 0x7F000000;
 #pragma unroll
             for (int sI = 0; sI < 4; ++sI) {
@@ -1278,7 +1289,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         idx[e] = (src < 0 || src >= wn) ? wcap * SW : src * SW;
     }
     for (int e = tid; e < ROWS; e += DEEP_NTH) idx[9 * ROWS + e] = tok0 + e < a.Lout ? e * SK : ROWS * SK;
-    for (int e = tid; e < Cmain; e += DEEP_NTH) lwin[wcap * SW + e] = 0.f;
+    for (int e = tid; e < Cs; e += DEEP_NTH) lwin[wcap * SW + e] = 0.f;
     if (Cskip)
         for (int e = tid; e < Cskip; e += DEEP_NTH) lraw[ROWS * SK + e] = 0.f;
     if (do_gn && tid < 96) {                                       // input statistics: the 8 copies added up (first use of a loaded value)
@@ -1343,7 +1354,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
                     y[k] = act ? deep_silu(t) : t;
                 }
             }
-            *reinterpret_cast<f32x4*>(lwin + row * SW + c4) = y;
+            *reinterpret_cast<f32x4*>(lwin + row * SW + c4l) = y;
         };
 #pragma unroll
         for (int u = 0; u < MAXR; ++u) {
@@ -1468,11 +1479,53 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         for (int e = tid; e < a.nstat * 96 * 2; e += DEEP_NTH) st[e] = 0.0;
         if (a.nstat) __syncthreads();
     }
-    if (e_on) {                                               // (same order of additions as before: partials in wave order, bias, bias2, per-clip bias, residual)
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (e_on) {                                               // (partials in wave order)
         const float* rp = red + e_rr * LDR + 4 * e_cq;
-        f32x4 v = *reinterpret_cast<const f32x4*>(rp);
+        v = *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
         for (int w = 1; w < 8; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
+    }
+    if (KS > 1) {
+        // cross-workgroup split-K completed inside the launch, k_conv's protocol (conv.hip; cdna_hip_programming.md G16, form R1): park the
+        // partial tile with write-through 8-byte stores, drain, ONE ticket per workgroup; the workgroup that draws the last ticket of its
+        // tile re-reads the KS partials past its L1 / L2 and sums them in slice order (the result does not depend on who is last)
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        const size_t sstride = (size_t)a.B * a.Lout * a.N;
+        const size_t eoff = ((size_t)b * a.Lout + e_tok) * a.N + e_n;
+        if (e_on) {
+            gu64* dst = (gu64*)(unsigned long long)(a.slab + (size_t)z * sstride + eoff);
+            __hip_atomic_store(dst, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const s_last = reinterpret_cast<int*>(scratch);     // (the flag word of the statistics scratch: dynamic LDS -- the launch may ask for all 160 KB)
+        int* ticket = a.tickets + ((size_t)b * a.tiles_per_b + (tok0 / ROWS)) * a.tiles_n + ct;
+        if (tid == 0) *s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == KS - 1;
+        __syncthreads();
+        if (!*s_last) return;
+        if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-cleaning for the next launch
+        if (e_on) {
+            gu64* src = (gu64*)(unsigned long long)(a.slab + eoff);
+            unsigned long long t0[4], t1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = k < KS;
+                t0[k] = in ? __hip_atomic_load(src + (size_t)k * (sstride / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                t1[k] = in ? __hip_atomic_load(src + (size_t)k * (sstride / 2) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[0] += __uint_as_float((unsigned)t0[k]);
+                v[1] += __uint_as_float((unsigned)(t0[k] >> 32));
+                v[2] += __uint_as_float((unsigned)t1[k]);
+                v[3] += __uint_as_float((unsigned)(t1[k] >> 32));
+            }
+        }
+    }
+    if (e_on) {                                               // (same order of additions as before: bias, bias2, per-clip bias, residual)
         v += e_add;
         if (a.bias2) v += e_b2;
         if (a.bias_b) v += e_bb;
@@ -2029,8 +2082,8 @@ hipError_t launch_deep_attn(const DeepAttnArgs& a0, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ---- k_conv_win (ConvTile{MT, NT, NW = 80, KS = 1, XM}) ----
-static size_t conv_win_layout(const ConvArgs& a, int MT, int NT, int* wcap_out) {
+// ---- k_conv_win (ConvTile{MT, NT, NW = 80, KS = 1 | 2 | 4, XM}) ----
+static size_t conv_win_layout(const ConvArgs& a, int MT, int NT, int KS, int* wcap_out) {
     const int ROWS = 16 * MT, COLS = 16 * NT;
     int wcap = 1;                                           // the tallest window of any row tile (same arithmetic as the kernel)
     for (int tok0 = 0; tok0 < a.Lout; tok0 += ROWS) {
@@ -2040,7 +2093,7 @@ static size_t conv_win_layout(const ConvArgs& a, int MT, int NT, int* wcap_out) 
         wcap = n > wcap ? n : wcap;
     }
     if (wcap_out) *wcap_out = wcap;
-    size_t fl = (size_t)(wcap + 1) * (a.Cmain + DEEP_PAD);
+    size_t fl = (size_t)(wcap + 1) * (a.Cmain / KS + DEEP_PAD);
     if (a.Cskip) fl += (size_t)(ROWS + 1) * (a.Cskip + DEEP_PAD);
     fl += 10 * ROWS + 384 + 192;                                        // row table | statistics (doubles) | (mean, rstd)
     const size_t red = (size_t)8 * ROWS * (COLS + 4) + DEEP_FIN_FLOATS;
@@ -2067,8 +2120,12 @@ int conv_win_selftest(int r, int t, bool up, int Lout, int Lsrc) {
     return 0;
 }
 
-bool conv_win_eligible(const ConvArgs& a, int MT, int NT) {
+bool conv_win_eligible(const ConvArgs& a, int MT, int NT, int KS) {
     if (!((MT == 1 && (NT == 2 || NT == 4)) || (MT == 2 && (NT == 2 || NT == 4)))) return false;       // (2 x 4: round 6, with a 2 x 2-chunk weight ring)
+    if (KS != 1 && KS != 2 && KS != 4) return false;
+    // K slices: whole 16-channel chunks per slice, no fused skip conv (its rows would belong to one slice only), slab + counters of the plan
+    // (the plan attaches them to every conv, finish_split_k: checked at launch, not here -- tiles are chosen before that)
+    if (KS > 1 && (a.Cskip || (a.Cmain / 16) % KS || (a.N & 3))) return false;
     if (a.ntaps != 9 || (a.geo_main != 1 && a.geo_main != 2) || a.out_cm || a.ddim || a.N % (16 * NT) || (a.Cmain & 15) || (a.Cskip & 15) || a.Cmain > 2048) return false;
     if (a.nmain == 2 && (a.C[0] & 3)) return false;
     if (a.nskip == 2 && (a.C[2] & 3)) return false;
@@ -2076,16 +2133,16 @@ bool conv_win_eligible(const ConvArgs& a, int MT, int NT) {
     for (int t = 0; t < a.nstat; ++t)
         if (a.stat[t].coff & 3) return false;
     if ((long)(9 * a.Cmain + a.Cskip) * a.ldw * 4 >= 0x7F000000L) return false;
-    return conv_win_layout(a, MT, NT, nullptr) <= 160 * 1024;
+    return conv_win_layout(a, MT, NT, KS, nullptr) <= 160 * 1024;
 }
-size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_win_layout(a, t.MT, t.NT, nullptr); }
+size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_win_layout(a, t.MT, t.NT, t.KS < 1 ? 1 : t.KS, nullptr); }
 
 template <int MT, int NT>
-static hipError_t conv_win_launch_t(const ConvArgs& a0, int xm, hipStream_t s) {
+static hipError_t conv_win_launch_t(const ConvArgs& a0, int xm, int KS, hipStream_t s) {
     ConvArgs a = a0;
-    if (!conv_win_eligible(a, MT, NT)) return hipErrorInvalidValue;
+    if (!conv_win_eligible(a, MT, NT, KS) || (KS > 1 && (!a.slab || !a.tickets))) return hipErrorInvalidValue;
     const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT), tiles_n = a.N / (16 * NT);
-    a.KS = 1;
+    a.KS = KS;
     a.xmap = 0;
     if (xm) {                                               // (a grid the XCD map does not tile keeps the plain order)
         const long nblk = (long)a.B * tiles * tiles_n;
@@ -2103,23 +2160,26 @@ static hipError_t conv_win_launch_t(const ConvArgs& a0, int xm, hipStream_t s) {
     a.Bt = a.B * tiles;
     a.inv_tiles_per_b = 1.0f / (float)tiles;
     a.inv_Bt = 1.0f / (float)a.Bt;
-    a.cpt = a.Cmain / 16;
+    a.cps_r = a.Cmain / KS;                                  // channels of a K slice; the kernel's chunk walk is per slice:
+    a.cpt = a.cps_r / 16;                                    // 16-channel chunks per tap and slice
     a.inv_cpt = 1.0f / (float)a.cpt;
+    a.inv_tiles_n = 1.0f / (float)(a.Bt * tiles_n);          // (block -> K slice)
     a.geo_inv_r = 1.0f / (float)a.geo_r;
     int wcap = 0;
-    const size_t smem = conv_win_layout(a, MT, NT, &wcap);
+    const size_t smem = conv_win_layout(a, MT, NT, KS, &wcap);
     a.rec_cap = wcap;
-    if ((long)a.Bt * tiles_n >= (1L << 21)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_conv_win<MT, NT>), dim3((unsigned)(a.Bt * tiles_n)), dim3(DEEP_NTH), smem, s, a);
+    if ((long)a.Bt * tiles_n * KS >= (1L << 21)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_conv_win<MT, NT>), dim3((unsigned)(a.Bt * tiles_n * KS)), dim3(DEEP_NTH), smem, s, a);
     return hipGetLastError();
 }
 hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s) {
     static const int env_xm = getenv("MTV_WIN_XM") ? atoi(getenv("MTV_WIN_XM")) : -1;       // (A/B hook: block order of every k_conv_win launch)
     if (env_xm >= 0) t.XM = env_xm;
-    if (t.MT == 1 && t.NT == 4) return conv_win_launch_t<1, 4>(a, t.XM, s);
-    if (t.MT == 1 && t.NT == 2) return conv_win_launch_t<1, 2>(a, t.XM, s);
-    if (t.MT == 2 && t.NT == 2) return conv_win_launch_t<2, 2>(a, t.XM, s);
-    if (t.MT == 2 && t.NT == 4) return conv_win_launch_t<2, 4>(a, t.XM, s);
+    const int KS = t.KS < 1 ? 1 : t.KS;
+    if (t.MT == 1 && t.NT == 4) return conv_win_launch_t<1, 4>(a, t.XM, KS, s);
+    if (t.MT == 1 && t.NT == 2) return conv_win_launch_t<1, 2>(a, t.XM, KS, s);
+    if (t.MT == 2 && t.NT == 2) return conv_win_launch_t<2, 2>(a, t.XM, KS, s);
+    if (t.MT == 2 && t.NT == 4) return conv_win_launch_t<2, 4>(a, t.XM, KS, s);
     return hipErrorInvalidValue;
 }
 

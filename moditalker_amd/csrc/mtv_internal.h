@@ -442,7 +442,7 @@ hipError_t launch_conv_x3(const ConvArgs& a, ConvTile t, hipStream_t s);
 hipError_t launch_conv_x3_geglu(const ConvArgs& a, ConvTile t, const float* h, hipStream_t s);
 hipError_t launch_split_w3(const float* W, void* W3, size_t plane_bytes, int row0, int rows, int ldw, hipStream_t s);
 // k_conv_win (deep.hip): 3x3 convs of the large levels with the transformed input window staged in LDS -- ConvTile NW == 80
-bool conv_win_eligible(const ConvArgs& a, int MT, int NT);
+bool conv_win_eligible(const ConvArgs& a, int MT, int NT, int KS = 1);     // KS = ConvTile::KS of the tile: K slices (1 | 2 | 4)
 int conv_win_selftest(int r, int t, bool up, int Lout, int Lsrc);      // host-only check of the window arithmetic (0 = ok)
 size_t conv_win_smem_bytes(const ConvArgs& a, ConvTile t);
 hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s);

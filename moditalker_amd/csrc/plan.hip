@@ -1090,7 +1090,7 @@ struct Builder {
 static int g_force_wm = -1, g_force_wn = 0;
 static int g_force_b3[3] = {-1, 0, 1};       // MTV_FORCE_B3="MT,NT[,KS]" (or mtv_debug_force_b3): every eligible conv on the split-bf16 kernel k_conv_x3<MT, NT>
 static int g_force_pw[3] = {-1, 0, 1};         // MTV_FORCE_PW="MT,NTW" (or mtv_debug_force_pw): every eligible 1x1 conv on k_conv_pw<MT, NTW>
-static int g_force_win[2] = {-1, 0};        // MTV_FORCE_WIN="MT,NT" (or mtv_debug_force_win): every eligible 3x3 conv on k_conv_win<MT, NT>
+static int g_force_win[3] = {-1, 0, 1};     // MTV_FORCE_WIN="MT,NT[,KS]" (or mtv_debug_force_win / _ks): every eligible 3x3 conv on k_conv_win<MT, NT>
 static int g_force_lin[3] = {-1, 0, 0};     // MTV_FORCE_LIN="MT,NT,NWV" (or mtv_debug_force_lin): every eligible 1x1 conv on k_lin<MT, NT, NWV>
 static void parse_force_b3() {
     if (g_force_b3[0] != -1) return;
@@ -1125,14 +1125,18 @@ void force_lds_tile(const ConvArgs& a, ConvTile* t) {
     if (g_force_win[0] == -1) {
         g_force_win[0] = 0;
         if (const char* e = getenv("MTV_FORCE_WIN")) {
-            int x = 0, y = 0;
-            if (sscanf(e, "%d,%d", &x, &y) == 2 && (x == 1 || x == 2) && (y == 2 || y == 4)) { g_force_win[0] = x; g_force_win[1] = y; }
+            int x = 0, y = 0, z = 1;
+            if (sscanf(e, "%d,%d,%d", &x, &y, &z) >= 2 && (x == 1 || x == 2) && (y == 2 || y == 4) && (z == 1 || z == 2 || z == 4)) { g_force_win[0] = x; g_force_win[1] = y; g_force_win[2] = z; }
         }
     }
-    if (g_force_win[0] > 0 && conv_win_eligible(a, g_force_win[0], g_force_win[1])) {
+    if (g_force_win[0] > 0) {
         static const int xm = getenv("MTV_FORCE_WIN_XM") ? atoi(getenv("MTV_FORCE_WIN_XM")) != 0 : 0;      // (with the XCD-aware block order)
-        *t = ConvTile{g_force_win[0], g_force_win[1], 80, 1, xm};
-        return;
+        // (K slices where the conv can take them -- no fused skip conv, whole chunks per slice -- else the unsliced tile)
+        const int ks = conv_win_eligible(a, g_force_win[0], g_force_win[1], g_force_win[2]) ? g_force_win[2] : 1;
+        if (conv_win_eligible(a, g_force_win[0], g_force_win[1], ks)) {
+            *t = ConvTile{g_force_win[0], g_force_win[1], 80, ks, xm};
+            return;
+        }
     }
     if (g_force_pw[0] == -1) {
         g_force_pw[0] = 0;
@@ -1173,7 +1177,7 @@ int finish_split_k(mtv_ctx* c, Plan* plan) {
         const size_t one = (size_t)B * op->a.Lout * op->a.N;
         size_t ks = 16;
         while (ks > 1 && ks * one * 4 > ((size_t)64 << 20)) ks /= 2;
-        if (op->t.NW != 64 && op->t.NW != 80 && op->t.NW != 96 && (size_t)op->t.KS > ks) ks = op->t.KS;      // (k_lin's / k_conv_pw's KS is a wave count, k_conv_win never splits K)
+        if (op->t.NW != 64 && op->t.NW != 96 && (size_t)op->t.KS > ks) ks = op->t.KS;      // (k_lin's / k_conv_pw's KS is a wave count)
         if (ks < 2) continue;                       // never split: needs no slab (the autoencoder's 16384-token GEMMs)
         need = ks * one > need ? ks * one : need;
     }
@@ -1301,7 +1305,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const bool tiled_ok = t.NW == 32 && (t.MT == 2 || t.MT == 4) && (t.NT == 2 || t.NT == 4 || t.NT == 8) && t.KS == 1 && t.XM == 0 && conv_lds_eligible(a);
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
             const bool b3_ok = t.NW == 48 && !(a.B == 1 && a.Lout <= 2048) && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
-            const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && t.KS == 1 && (t.XM == 0 || t.XM == 1) && conv_win_eligible(a, t.MT, t.NT);
+            const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && (t.XM == 0 || t.XM == 1) && conv_win_eligible(a, t.MT, t.NT, t.KS);
             const bool pw_ok = t.NW == 96 && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 6) && t.XM == 0 && conv_pw_eligible(a, t.MT, t.NT, t.KS);
             const bool shape_ok = tiled_ok || lin_ok || b3_ok || win_ok || pw_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
@@ -1425,10 +1429,14 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                 // block order by rule, not by timing (it moves L2 misses, not time: profiles/r04_conv_win_xcd_order.txt): one XCD per
                 // weight column tile where the weights are the larger operand
                 const int XM = wbytes >= abytes ? 1 : 0;
-                for (auto& mn : tw) {
-                    if (!conv_win_eligible(a, mn[0], mn[1])) continue;
-                    const ConvTile t{mn[0], mn[1], 80, 1, XM};
-                    if ((long)a.B * ((a.Lout + 16 * t.MT - 1) / (16 * t.MT)) * (a.N / (16 * t.NT)) < 64) continue;
+                for (auto& mn : tw)
+                  for (int KS = 1; KS <= 4; KS *= 2) {
+                    // K slices (round 6) only while the tiles alone leave CUs idle, slices of at least 3 x 9 chunks, within the slab
+                    if (!conv_win_eligible(a, mn[0], mn[1], KS)) continue;
+                    const ConvTile t{mn[0], mn[1], 80, KS, XM};
+                    const long ntile = (long)a.B * ((a.Lout + 16 * t.MT - 1) / (16 * t.MT)) * (a.N / (16 * t.NT));
+                    if (ntile * KS < 64) continue;
+                    if (KS > 1 && (ntile * KS > 256 || a.Cmain / 16 / KS < 3 || (size_t)KS * a.B * a.Lout * a.N > slab_cap)) continue;
                     float samp[16];
                     HIPCHK(run(t));
                     for (int w = 0; w < nsamp; ++w) {
@@ -2346,12 +2354,14 @@ int mtv_debug_force_pw_waves(int mt, int ntw, int waves) {
     return MTV_OK;
 }
 
-int mtv_debug_force_win(int mt, int nt) {
+int mtv_debug_force_win_ks(int mt, int nt, int ks) {
     if (mt == 0) { g_force_win[0] = 0; return MTV_OK; }
     if (!((mt == 1 || mt == 2) && (nt == 2 || nt == 4))) return fail(MTV_ERR_INVALID, "k_conv_win tile must be 1x2, 1x4, 2x2 or 2x4");
-    g_force_win[0] = mt; g_force_win[1] = nt;
+    if (ks != 1 && ks != 2 && ks != 4) return fail(MTV_ERR_INVALID, "k_conv_win runs 1, 2 or 4 K slices");
+    g_force_win[0] = mt; g_force_win[1] = nt; g_force_win[2] = ks;
     return MTV_OK;
 }
+int mtv_debug_force_win(int mt, int nt) { return mtv_debug_force_win_ks(mt, nt, 1); }
 
 int mtv_debug_force_lds(int wm, int wn) {
     if (wm == 0) { g_force_wm = 0; return MTV_OK; }

@@ -577,6 +577,16 @@ def test_window_staged_conv_kernel_vs_reference_golden(mt, nt):
     _forced("mtv_debug_force_win", (mt, nt), (0, 0), f"k_conv_win<{mt},{nt}>", expect)
 
 
+@pytest.mark.parametrize("mt,nt,ks", [(2, 4, 4), (2, 2, 2), (1, 4, 2)])
+def test_window_staged_conv_kernel_with_k_slices_vs_reference_golden(mt, nt, ks):
+    """k_conv_win with 2 / 4 K slices per tile (round 6: slice z stages its 1 / ks of the input channels, partial tiles meet in the plan's
+    split-K slab inside the launch, the last slice sums them in slice order and runs the epilogue) forced onto every 3x3 conv that can take
+    them (no fused skip conv); same references as the unsliced kernel.  The sum order is fixed: repeats are bit-equal."""
+    def expect(names):
+        assert sum(f",80,{ks}]" in n or f",80,{ks}x]" in n for n in names) >= 10, "the K-sliced window-staged kernel was not selected"
+    _forced("mtv_debug_force_win_ks", (mt, nt, ks), (0, 0, 1), f"k_conv_win<{mt},{nt}> ks{ks}", expect)
+
+
 @pytest.mark.parametrize("mt,ntw,waves", [(1, 1, 8), (1, 2, 8), (2, 2, 8), (2, 1, 6), (1, 1, 4), (2, 1, 4), (1, 1, 2)])
 def test_pointwise_conv_kernel_vs_reference_golden(mt, ntw, waves):
     """k_conv_pw<MT, NTW, NWA> (csrc/deep.hip: the rows of a tile normalised once into LDS, NWA of the 8 waves side by side along N -- column
