@@ -1155,8 +1155,8 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     // tile is fetched by ONE L2 (tiles_n a multiple of 8: Sx column tiles per XCD) or by 8 / tiles_n of them (tiles_n = 2^Sx < 8) and
     // the (smaller) activation windows are what the XCDs re-read.  Speed only.
     DEEP_STAMP(0);
-    // K slices (ConvTile::KS = 2 / 4, round 6; convs without a fused skip conv): slice z = the z-th 1 / KS of the input channels, all nine
-    // taps -- its window holds only those channels -- and the slices of a tile are Bt x tiles_n workgroups apart (each slice keeps the
+    // K slices (ConvTile::KS = 2 / 4, round 6): slice z = the z-th 1 / KS of the input channels, all nine taps, and the z-th 1 / KS of the
+    // fused skip conv's channels -- its window and raw rows hold only those channels -- and the slices of a tile are Bt x tiles_n workgroups apart (each slice keeps the
     // block order below).  Partial tiles meet in the slab exactly as k_conv's (write-through stores, one ticket per tile, the last slice
     // sums them in slice order and runs the epilogue).
     const int KS = deep_usgpr(a.KS);
@@ -1185,7 +1185,8 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     const int tok0 = (brt - b * a.tiles_per_b) * ROWS, n0 = ct * COLS;
     const int Cmain = a.Cmain, Cskip = a.Cskip;
     const int Cs = a.cps_r, coff = z * Cs;                 // this slice's channels [coff, coff + Cs) (Cs = Cmain without K slices)
-    const int SW = Cs + DEEP_PAD, SK = Cskip + DEEP_PAD;
+    const int Css = a.cps_q, soff = z * Css;               // ... and of the fused skip conv's channels [soff, soff + Css)
+    const int SW = Cs + DEEP_PAD, SK = Css + DEEP_PAD;
     DEEP_STAMP(1);
     const int wcap = a.rec_cap;                            // window capacity in rows (host); row wcap of the window = zeros
     float* const lwin = smem;                              // [wcap + 1][SW]
@@ -1230,9 +1231,9 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     }
     constexpr int SRN = 4;                                 // raw skip quads in flight per thread (first pass: 16 MT rows x up to 512 / MT channels)
     f32x4 sraw[SRN];
-    const int QS = Cskip >> 2, C2 = a.C[2];
+    const int QS = Css >> 2, C2 = a.C[2];
     auto skip_ptr = [&](int e) {
-        const int row = e / QS, c = 4 * (e - row * QS);
+        const int row = e / QS, c = soff + 4 * (e - row * QS);
         return c < C2 ? a.src[2] + ((size_t)b * a.Lskip + tok0 + row) * C2 + c : a.src[3] + ((size_t)b * a.Lskip + tok0 + row) * a.C[3] + (c - C2);
     };
     if (Cskip) {
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
                 sraw[u] = *reinterpret_cast<const f32x4*>(skip_ptr(e < ROWS * QS && tok0 + e / QS < a.Lout ? e : 0));
         }
     }
-    const int cpt = a.cpt, nmain_ch = 9 * cpt, nch = nmain_ch + (Cskip >> 4);
+    const int cpt = a.cpt, nmain_ch = 9 * cpt, nch = nmain_ch + (Css >> 4);
     const int n_it = (nch + 7) >> 3;
     const int wrows = 9 * Cmain + Cskip;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, wrows * a.ldw * 4, 0x00020000);
@@ -1254,7 +1255,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
             const int c = wave + 8 * kc;
             // W row of the chunk's first channel: tap-major over the concatenated main channels, then the skip channels (k_conv's
             // order of rows); a chunk past the end reads out of range = zeros
-            int krow = 9 * Cmain + (c - nmain_ch) * 16;
+            int krow = 9 * Cmain + soff + (c - nmain_ch) * 16;
             if (c < nmain_ch) { const int tap = FDiv{a.inv_cpt}(c, cpt); krow = tap * Cmain + coff + (c - tap * cpt) * 16; }
             const int soff = c < nch ? krow * a.ldw * 4 : 0x7F000000;
 #pragma unroll
@@ -1291,7 +1292,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
     for (int e = tid; e < ROWS; e += DEEP_NTH) idx[9 * ROWS + e] = tok0 + e < a.Lout ? e * SK : ROWS * SK;
     for (int e = tid; e < Cs; e += DEEP_NTH) lwin[wcap * SW + e] = 0.f;
     if (Cskip)
-        for (int e = tid; e < Cskip; e += DEEP_NTH) lraw[ROWS * SK + e] = 0.f;
+        for (int e = tid; e < Css; e += DEEP_NTH) lraw[ROWS * SK + e] = 0.f;
     if (do_gn && tid < 96) {                                       // input statistics: the 8 copies added up (first use of a loaded value)
         f64x2 v0 = vraw[0];
 #pragma unroll
@@ -2094,7 +2095,7 @@ static size_t conv_win_layout(const ConvArgs& a, int MT, int NT, int KS, int* wc
     }
     if (wcap_out) *wcap_out = wcap;
     size_t fl = (size_t)(wcap + 1) * (a.Cmain / KS + DEEP_PAD);
-    if (a.Cskip) fl += (size_t)(ROWS + 1) * (a.Cskip + DEEP_PAD);
+    if (a.Cskip) fl += (size_t)(ROWS + 1) * (a.Cskip / KS + DEEP_PAD);
     fl += 10 * ROWS + 384 + 192;                                        // row table | statistics (doubles) | (mean, rstd)
     const size_t red = (size_t)8 * ROWS * (COLS + 4) + DEEP_FIN_FLOATS;
     return (fl > red ? fl : red) * 4 + 64;
@@ -2123,9 +2124,9 @@ int conv_win_selftest(int r, int t, bool up, int Lout, int Lsrc) {
 bool conv_win_eligible(const ConvArgs& a, int MT, int NT, int KS) {
     if (!((MT == 1 && (NT == 2 || NT == 4)) || (MT == 2 && (NT == 2 || NT == 4)))) return false;       // (2 x 4: round 6, with a 2 x 2-chunk weight ring)
     if (KS != 1 && KS != 2 && KS != 4) return false;
-    // K slices: whole 16-channel chunks per slice, no fused skip conv (its rows would belong to one slice only), slab + counters of the plan
-    // (the plan attaches them to every conv, finish_split_k: checked at launch, not here -- tiles are chosen before that)
-    if (KS > 1 && (a.Cskip || (a.Cmain / 16) % KS || (a.N & 3))) return false;
+    // K slices: whole 16-channel chunks of the tapped and of the skip channels per slice; slab + counters of the plan (attached to every
+    // conv by finish_split_k: checked at launch, not here -- tiles are chosen before that)
+    if (KS > 1 && ((a.Cskip / 16) % KS || (a.Cmain / 16) % KS || (a.N & 3))) return false;
     if (a.ntaps != 9 || (a.geo_main != 1 && a.geo_main != 2) || a.out_cm || a.ddim || a.N % (16 * NT) || (a.Cmain & 15) || (a.Cskip & 15) || a.Cmain > 2048) return false;
     if (a.nmain == 2 && (a.C[0] & 3)) return false;
     if (a.nskip == 2 && (a.C[2] & 3)) return false;
@@ -2160,7 +2161,8 @@ static hipError_t conv_win_launch_t(const ConvArgs& a0, int xm, int KS, hipStrea
     a.Bt = a.B * tiles;
     a.inv_tiles_per_b = 1.0f / (float)tiles;
     a.inv_Bt = 1.0f / (float)a.Bt;
-    a.cps_r = a.Cmain / KS;                                  // channels of a K slice; the kernel's chunk walk is per slice:
+    a.cps_q = a.Cskip / KS;                                  // skip / tapped channels of a K slice; the kernel's chunk walk is per slice:
+    a.cps_r = a.Cmain / KS;
     a.cpt = a.cps_r / 16;                                    // 16-channel chunks per tap and slice
     a.inv_cpt = 1.0f / (float)a.cpt;
     a.inv_tiles_n = 1.0f / (float)(a.Bt * tiles_n);          // (block -> K slice)

@@ -227,12 +227,12 @@ def test_committed_tile_table_is_well_formed():
             assert B * L >= 1024 and not (B == 1 and L <= 2048), line
         elif nw == 64:                    # k_lin<MT, NT, NWV>: 1x1 only
             assert taps == 1 and mt in (1, 2) and nt in (1, 2, 4) and ks in (1, 2, 4), line
-        elif nw == 80:                    # k_conv_win<MT, NT> (csrc/deep.hip): 3x3 only; KS = 2 | 4 K slices (round 6) only without a fused skip conv,
+        elif nw == 80:                    # k_conv_win<MT, NT> (csrc/deep.hip): 3x3 only; KS = 2 | 4 K slices (round 6):
             # whole 16-channel chunks per slice, at most one round of workgroups.  XM = the XCD-aware block order, set by rule: exactly where
             # the weights are the larger operand
             assert taps == 9 and (mt, nt) in ((1, 4), (1, 2), (2, 2), (2, 4)) and ks in (1, 2, 4) and N % (16 * nt) == 0, line
             if ks > 1:
-                assert Cs == 0 and (Cm // 16) % ks == 0 and N % 4 == 0 and B * -(-L // (16 * mt)) * (N // (16 * nt)) * ks <= 256, line
+                assert (Cs // 16) % ks == 0 and (Cm // 16) % ks == 0 and N % 4 == 0 and B * -(-L // (16 * mt)) * (N // (16 * nt)) * ks <= 256, line
             Ls, Lk = int(m.group(3)), int(m.group(4))
             assert xm == (1 if (taps * Cm + Cs) * N >= B * (Ls * Cm + Lk * Cs + L * N) else 0), line
         elif nw == 96:                    # k_conv_pw<MT, NTW, NWA> (csrc/deep.hip): 1x1 on identity rows, whole K per wave; KS = multiplying waves (1 = all 8)
