@@ -35,6 +35,7 @@ namespace mtv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+
 namespace {
 
 constexpr int DEEP_PAD = 8;          // LDS row stride = slice channels + 8 floats: the 16 lanes of a ds_read_b128 lane group hit
@@ -673,13 +674,13 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
         const size_t qoff = ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq;
         float* dst = outp + qoff;
         if (fin) deep_park_quad(dst, v);
-        else *reinterpret_cast<f32x4*>(dst) = v;          // (tagged completion too: consumers emitted before the plain copy was asked for read the slabs)
+        else mtv_store_out4(dst, v);          // (tagged completion too: consumers emitted before the plain copy was asked for read the slabs)
         if (tg) {
             if (s) {
                 deep_put_granules(grs, (unsigned)(((size_t)(s - 1) * slice_gran + qoff) * 8), v, epoch);
             } else {
                 deep_add_granules(grs, (unsigned)qoff, slice_gran, a.KS, epoch, a.fin.fault, v);      // slices 1 .. KS - 1, slice order
-                *reinterpret_cast<f32x4*>(a.fin.out + qoff) = v;
+                mtv_store_out4(a.fin.out + qoff, v);
                 deep_fin_stat(a.fin, fscratch, rg_tok0 + rr, n0 + 4 * cq, v);
             }
         }
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
                 const int tok = rg_tok0 + rr, n = n0 + 4 * cq;
                 const size_t off = ((size_t)b * a.Lout + tok) * a.N + n;
                 const f32x4 v = deep_gather_quad(a.out + off, a.out_slab_stride, a.KS);
-                *reinterpret_cast<f32x4*>(a.fin.out + off) = v;
+                mtv_store_out4(a.fin.out + off, v);
                 deep_fin_stat(a.fin, scratch, tok, n, v);
             }
             deep_fin_flush(a.fin, scratch, b, tid);
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(128) void k_deep_finalize(const DeepFinArgs a) {
 #pragma unroll
         for (int k = 1; k < 8; ++k)
             if (k < a.src.ks) v += t[k];                       // slab order
-        *reinterpret_cast<f32x4*>(a.out + off) = v;
+        mtv_store_out4(a.out + off, v);
     }
     if (!a.nstat) return;
     for (int e = tid; e < a.nstat * 96 * 2; e += 128) (&sdp[0][0][0])[e] = 0.0;
@@ -1067,13 +1068,13 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         const size_t qoff = ((size_t)b * L + tok) * C + n;
         float* dst = a.out + (size_t)hg * a.out_slab_stride + qoff;
         if (a.fin.out && !tg) deep_park_quad(dst, v);
-        else *reinterpret_cast<f32x4*>(dst) = v;
+        else mtv_store_out4(dst, v);
         if (tg) {
             if (hg) {
                 deep_put_granules(grs, (unsigned)(((size_t)(hg - 1) * slice_gran + qoff) * 8), v, epoch);
             } else {
                 deep_add_granules(grs, (unsigned)qoff, slice_gran, a.nhg, epoch, a.fin.fault, v);
-                *reinterpret_cast<f32x4*>(a.fin.out + qoff) = v;
+                mtv_store_out4(a.fin.out + qoff, v);
                 deep_fin_stat(a.fin, fscratch, tok, n, v);
             }
         }
@@ -1089,7 +1090,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
                 if (tok >= L) continue;
                 const size_t off = ((size_t)b * L + tok) * C + n;
                 const f32x4 v = deep_gather_quad(a.out + off, a.out_slab_stride, a.nhg);
-                *reinterpret_cast<f32x4*>(a.fin.out + off) = v;
+                mtv_store_out4(a.fin.out + off, v);
                 deep_fin_stat(a.fin, scratch, tok, n, v);
             }
             deep_fin_flush(a.fin, scratch, b, tid);
@@ -1531,7 +1532,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         if (a.bias2) v += e_b2;
         if (a.bias_b) v += e_bb;
         if (a.res) v += e_res;
-        *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + e_tok) * a.N + e_n) = v;
+        mtv_store_out4(a.out + ((size_t)b * a.Lout + e_tok) * a.N + e_n, v);
         if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, e_tok, e_n, v);
         if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, e_tok, e_n, v);
     }
@@ -1791,7 +1792,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
             f32x4 v = *reinterpret_cast<const f32x4*>(red + rr * LDR + 4 * cq);
             v += *reinterpret_cast<const f32x4*>(a.bias + n);
             if (a.res) v += e_res[u];
-            *reinterpret_cast<f32x4*>(a.out + ((size_t)b * a.Lout + tok) * a.N + n) = v;
+            mtv_store_out4(a.out + ((size_t)b * a.Lout + tok) * a.N + n, v);
             if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, tok, n, v);
             if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, tok, n, v);
         }

@@ -19,6 +19,7 @@
 namespace mtv {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256) void k_pool_down(const PoolArgs a) {
             }
         }
     const size_t o = ((size_t)b * a.seg_dst.L + tok) * a.C + c;
-    *reinterpret_cast<f32x4*>(a.out_act + o) = sa * 0.25f;
-    *reinterpret_cast<f32x4*>(a.out_x + o) = sx * 0.25f;
+    mtv_store_out4(a.out_act + o, sa * 0.25f);
+    mtv_store_out4(a.out_x + o, sx * 0.25f);
 }
 
 hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s) {
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
         float* op = a.out + ((size_t)b * a.L + start + q0 + j) * a.C + (size_t)h * D;
         if constexpr (D >= 16) {
 #pragma unroll
-            for (int o = 0; o < NOB; ++o) *reinterpret_cast<f32x4*>(op + 16 * o + 4 * g) = oacc[o] * inv;
+            for (int o = 0; o < NOB; ++o) mtv_store_out4(op + 16 * o + 4 * g, oacc[o] * inv);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)

@@ -124,6 +124,21 @@ struct ConvArgs {
 // memory (~1 us) and they serialise (load, wait, compute, load the next line, wait ...): three to four
 // dependent misses at the head of every launch.  One combined wait here, then every later s_load hits.
 #if defined(__HIPCC__)
+// Output tensors leave a kernel through WRITE-THROUGH 16-byte stores (sc0 sc1).  A plain store parks the line dirty in the XCD's L2 until the
+// write-back at the end of the launch; the next launch -- on other XCDs -- then reads a tensor that has only just started towards memory.
+// Written through, it is on its way while the launch still computes and the end-of-launch write-back finds nothing to do.  Same-box A/B of
+// the step (profiles/r06_write_through_stores_ab.txt): 1.997 -> 1.977 ms; non-temporal stores instead: slower (2.004).  -DMTV_OUT_PLAIN=1
+// restores the plain stores.
+typedef float mtv_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mtv_store_out4(float* p, const mtv_f32x4& v) {
+#if defined(MTV_OUT_PLAIN) && MTV_OUT_PLAIN
+    *reinterpret_cast<mtv_f32x4*>(p) = v;
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+#endif
+#if defined(__HIPCC__)
 template <int BYTES>
 __device__ __forceinline__ void touch_kernargs() {
     static_assert(BYTES <= 10 * 64, "argument block larger than 10 lines");
