@@ -602,7 +602,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
             for (int k = h + H; k < xks; k += H)
                 v += *reinterpret_cast<const f32x4*>(a.x.p + (size_t)k * a.x.slab_stride + ((size_t)b * L + tok) * a.x.C + n);
             if (h == 0) v += *reinterpret_cast<const f32x4*>(a.bp + n);
-            mtv_store_out4(outp + ((size_t)b * L + tok) * C + n, v);
+            mtv_store_out4(outp, ((size_t)b * L + tok) * C + n, v);
         }
         __syncthreads();                                                    // (LDS is reused by the next item)
     }

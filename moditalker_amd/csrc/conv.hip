@@ -382,7 +382,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
         // of the next step's FiLM row (nobody reads either any more in this step): fire-and-forget stores that
         // drain under the conv itself; the step's scalars are fetched for the epilogue
         for (long long e = (long long)blockIdx.x * NTH + tid; e < ddv.zero_vec4; e += (long long)gridDim.x * NTH)
-            mtv_store_out4(ddv.zero_arena + 4 * e, f32x4{0.f, 0.f, 0.f, 0.f});
+            mtv_store_out4(ddv.zero_arena, (size_t)(4 * e), f32x4{0.f, 0.f, 0.f, 0.f});
         if (step_now + 1 < ddv.n_steps) {
             const float* src = ddv.film_tab + (size_t)(step_now + 1) * ddv.film_total;
             for (int e = blockIdx.x * NTH + tid; e < ddv.film_total; e += gridDim.x * NTH) ddv.film_out[e] = src[e];
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
                 if (n + k < a.N) v[k] = epi(a, v[k], b, tok, rs, n + k);
         }
         if (!a.out_cm && n + 3 < a.N) {
-            mtv_store_out4(a.out + ((size_t)b * a.Lout + tok) * a.N + n, v);
+            mtv_store_out4(a.out, ((size_t)b * a.Lout + tok) * a.N + n, v);
         } else if (dd) {
             // sampler-step head (N == 4 == the sample's channels): v is eps; x <- DDIM update, in the external
             // layout and as channels 0..3 of the packed input of the next step's stem conv.  The (up to) four x and four

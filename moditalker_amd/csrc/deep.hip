@@ -674,13 +674,13 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
         const size_t qoff = ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq;
         float* dst = outp + qoff;
         if (fin) deep_park_quad(dst, v);
-        else mtv_store_out4(dst, v);          // (tagged completion too: consumers emitted before the plain copy was asked for read the slabs)
+        else mtv_store_out4(outp, qoff, v);          // (tagged completion too: consumers emitted before the plain copy was asked for read the slabs)
         if (tg) {
             if (s) {
                 deep_put_granules(grs, (unsigned)(((size_t)(s - 1) * slice_gran + qoff) * 8), v, epoch);
             } else {
                 deep_add_granules(grs, (unsigned)qoff, slice_gran, a.KS, epoch, a.fin.fault, v);      // slices 1 .. KS - 1, slice order
-                mtv_store_out4(a.fin.out + qoff, v);
+                mtv_store_out4(a.fin.out, qoff, v);
                 deep_fin_stat(a.fin, fscratch, rg_tok0 + rr, n0 + 4 * cq, v);
             }
         }
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
                 const int tok = rg_tok0 + rr, n = n0 + 4 * cq;
                 const size_t off = ((size_t)b * a.Lout + tok) * a.N + n;
                 const f32x4 v = deep_gather_quad(a.out + off, a.out_slab_stride, a.KS);
-                mtv_store_out4(a.fin.out + off, v);
+                mtv_store_out4(a.fin.out, off, v);
                 deep_fin_stat(a.fin, scratch, tok, n, v);
             }
             deep_fin_flush(a.fin, scratch, b, tid);
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(128) void k_deep_finalize(const DeepFinArgs a) {
 #pragma unroll
         for (int k = 1; k < 8; ++k)
             if (k < a.src.ks) v += t[k];                       // slab order
-        mtv_store_out4(a.out + off, v);
+        mtv_store_out4(a.out, off, v);
     }
     if (!a.nstat) return;
     for (int e = tid; e < a.nstat * 96 * 2; e += 128) (&sdp[0][0][0])[e] = 0.0;
@@ -1068,13 +1068,13 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         const size_t qoff = ((size_t)b * L + tok) * C + n;
         float* dst = a.out + (size_t)hg * a.out_slab_stride + qoff;
         if (a.fin.out && !tg) deep_park_quad(dst, v);
-        else mtv_store_out4(dst, v);
+        else mtv_store_out4(a.out + (size_t)hg * a.out_slab_stride, qoff, v);
         if (tg) {
             if (hg) {
                 deep_put_granules(grs, (unsigned)(((size_t)(hg - 1) * slice_gran + qoff) * 8), v, epoch);
             } else {
                 deep_add_granules(grs, (unsigned)qoff, slice_gran, a.nhg, epoch, a.fin.fault, v);
-                mtv_store_out4(a.fin.out + qoff, v);
+                mtv_store_out4(a.fin.out, qoff, v);
                 deep_fin_stat(a.fin, fscratch, tok, n, v);
             }
         }
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
                 if (tok >= L) continue;
                 const size_t off = ((size_t)b * L + tok) * C + n;
                 const f32x4 v = deep_gather_quad(a.out + off, a.out_slab_stride, a.nhg);
-                mtv_store_out4(a.fin.out + off, v);
+                mtv_store_out4(a.fin.out, off, v);
                 deep_fin_stat(a.fin, scratch, tok, n, v);
             }
             deep_fin_flush(a.fin, scratch, b, tid);
@@ -1384,6 +1384,24 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
             if (tok0 + row < a.Lout) *reinterpret_cast<f32x4*>(lraw + row * SK + c) = *reinterpret_cast<const f32x4*>(skip_ptr(e));
         }
     }
+    // ---- epilogue operands of this thread's output quad, requested BEFORE the K loop (round 6; they were requested after it, and the
+    // residual -- written by an earlier launch, a first-touch miss like every read of a launch -- arrived after the partial tiles had been exchanged:
+    // the wait sat on the launch's tail.  16 registers held across the loop.)
+    constexpr int QPR = COLS / 4;
+    static_assert(ROWS * QPR <= DEEP_NTH, "one output quad per thread");
+    const int e_rr = tid / QPR, e_cq = tid - e_rr * QPR;
+    const int e_tok = tok0 + e_rr, e_n = n0 + 4 * e_cq;
+    const bool e_on = tid < ROWS * QPR && e_tok < a.Lout;
+    f32x4 e_add = {0.f, 0.f, 0.f, 0.f}, e_b2 = e_add, e_bb = e_add, e_res = e_add;
+    if (e_on) {
+        e_add = *reinterpret_cast<const f32x4*>(a.bias + e_n);
+        if (a.bias2) e_b2 = *reinterpret_cast<const f32x4*>(a.bias2 + e_n);
+        if (a.bias_b) e_bb = *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + e_n);
+        if (a.res) {
+            const int rs = a.geo_skip ? (geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, e_tok, 1, 1, true) & 0x0FFFFFFF) : e_tok;
+            e_res = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + rs) * a.N + e_n);
+        }
+    }
     __syncthreads();
     // ---- K loop: A fragments from the window (one chunk ahead), weights of iteration k + 2G replace those of k
     DEEP_STAMP(5);
@@ -1440,22 +1458,6 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
             if (G + g < rem) step(k + G + g, (G + g) & 1, bq[1][g]);
     }
     DEEP_STAMP(6);
-    // ---- epilogue operands of this thread's output quad, requested before the partial tiles are exchanged (a round trip off the tail)
-    constexpr int QPR = COLS / 4;
-    static_assert(ROWS * QPR <= DEEP_NTH, "one output quad per thread");
-    const int e_rr = tid / QPR, e_cq = tid - e_rr * QPR;
-    const int e_tok = tok0 + e_rr, e_n = n0 + 4 * e_cq;
-    const bool e_on = tid < ROWS * QPR && e_tok < a.Lout;
-    f32x4 e_add = {0.f, 0.f, 0.f, 0.f}, e_b2 = e_add, e_bb = e_add, e_res = e_add;
-    if (e_on) {
-        e_add = *reinterpret_cast<const f32x4*>(a.bias + e_n);
-        if (a.bias2) e_b2 = *reinterpret_cast<const f32x4*>(a.bias2 + e_n);
-        if (a.bias_b) e_bb = *reinterpret_cast<const f32x4*>(a.bias_b + (size_t)b * a.bias_b_stride + e_n);
-        if (a.res) {
-            const int rs = a.geo_skip ? (geo_source_t<FDiv>(FDiv{a.geo_inv_r}, a.geo_r, a.geo_t, e_tok, 1, 1, true) & 0x0FFFFFFF) : e_tok;
-            e_res = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + rs) * a.N + e_n);
-        }
-    }
     __syncthreads();
     // ---- the eight partial tiles -> (row, col) images (lane (i, q) holds, for row 4q + r, the NT consecutive columns NT i ..)
     constexpr int LDR = COLS + 4;
@@ -1532,7 +1534,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         if (a.bias2) v += e_b2;
         if (a.bias_b) v += e_bb;
         if (a.res) v += e_res;
-        mtv_store_out4(a.out + ((size_t)b * a.Lout + e_tok) * a.N + e_n, v);
+        mtv_store_out4(a.out, ((size_t)b * a.Lout + e_tok) * a.N + e_n, v);
         if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, e_tok, e_n, v);
         if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, e_tok, e_n, v);
     }
@@ -1715,14 +1717,18 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
     }
     // epilogue operands of this thread's first output quad: requested before the K loop's barrier (a round trip off the tail)
     constexpr int QPR = COLS / 4, NQ = ROWS * QPR, EPT = (NQ + DEEP_NTH - 1) / DEEP_NTH;
-    f32x4 e_res[EPT];
+    // (the bias too -- round 6: read inside the epilogue loop it was a first-touch miss on the launch's tail: every kernel starts on invalidated caches)
+    f32x4 e_res[EPT], e_bias[EPT];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
         e_res[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        e_bias[u] = e_res[u];
         const int e = tid + u * DEEP_NTH;
         const int rr = e / QPR, cq = e - rr * QPR;
-        if (a.res && e < NQ && tok0 + rr < a.Lout && n0 + 4 * cq < a.N)
-            e_res[u] = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + tok0 + rr) * a.N + n0 + 4 * cq);
+        if (e < NQ && tok0 + rr < a.Lout && n0 + 4 * cq < a.N) {
+            e_bias[u] = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * cq);
+            if (a.res) e_res[u] = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + tok0 + rr) * a.N + n0 + 4 * cq);
+        }
     }
     __syncthreads();
     DEEP_STAMP(5);
@@ -1790,9 +1796,9 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
         const int tok = tok0 + rr, n = n0 + 4 * cq;
         if (e < NQ && tok < a.Lout && n < a.N) {
             f32x4 v = *reinterpret_cast<const f32x4*>(red + rr * LDR + 4 * cq);
-            v += *reinterpret_cast<const f32x4*>(a.bias + n);
+            v += e_bias[u];
             if (a.res) v += e_res[u];
-            mtv_store_out4(a.out + ((size_t)b * a.Lout + tok) * a.N + n, v);
+            mtv_store_out4(a.out, ((size_t)b * a.Lout + tok) * a.N + n, v);
             if (a.nstat > 0) deep_stat_one(a.stat[0], 0, a.seg_out, scratch, tok, n, v);
             if (a.nstat > 1) deep_stat_one(a.stat[1], 1, a.seg_out, scratch, tok, n, v);
         }

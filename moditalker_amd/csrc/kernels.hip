@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void k_pool_down(const PoolArgs a) {
             }
         }
     const size_t o = ((size_t)b * a.seg_dst.L + tok) * a.C + c;
-    mtv_store_out4(a.out_act + o, sa * 0.25f);
-    mtv_store_out4(a.out_x + o, sx * 0.25f);
+    mtv_store_out4(a.out_act, o, sa * 0.25f);
+    mtv_store_out4(a.out_x, o, sx * 0.25f);
 }
 
 hipError_t launch_pool_down(const PoolArgs& a, hipStream_t s) {
@@ -646,10 +646,11 @@ __global__ __launch_bounds__(64 * QW * KSP) void k_attention(const AttnArgs a) {
     ATT_STAMP(4);
     const float inv = 1.0f / lsum;
     if (q0 + j < len) {
-        float* op = a.out + ((size_t)b * a.L + start + q0 + j) * a.C + (size_t)h * D;
+        const size_t opi = ((size_t)b * a.L + start + q0 + j) * a.C + (size_t)h * D;
+        float* op = a.out + opi;
         if constexpr (D >= 16) {
 #pragma unroll
-            for (int o = 0; o < NOB; ++o) mtv_store_out4(op + 16 * o + 4 * g, oacc[o] * inv);
+            for (int o = 0; o < NOB; ++o) mtv_store_out4(a.out, opi + 16 * o + 4 * g, oacc[o] * inv);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)

@@ -127,14 +127,23 @@ struct ConvArgs {
 // Output tensors leave a kernel through WRITE-THROUGH 16-byte stores (sc0 sc1).  A plain store parks the line dirty in the XCD's L2 until the
 // write-back at the end of the launch; the next launch -- on other XCDs -- then reads a tensor that has only just started towards memory.
 // Written through, it is on its way while the launch still computes and the end-of-launch write-back finds nothing to do.  Same-box A/B of
-// the step (profiles/r06_write_through_stores_ab.txt): 1.997 -> 1.977 ms; non-temporal stores instead: slower (2.004).  -DMTV_OUT_PLAIN=1
+// the step (profiles/r06_write_through_stores_ab.txt): 1.990 -> 1.980 ms; non-temporal stores instead: slower.  -DMTV_OUT_PLAIN=1
 // restores the plain stores.
+// `base` must be wave-uniform (a kernel argument, or one plus a workgroup-uniform slab offset): it becomes a buffer descriptor; `idx` = float
+// index of the quad (byte offset < 4 GB).  The store is the compiler's own raw-buffer store with the cache-policy operand -- NOT inline
+// assembly: the waitcnt pass does not see a memory operation inside an asm statement, so an asm store between loads makes the compiler's
+// vmcnt(N) waits pass early (a first version of this helper did exactly that: parity broke in every kernel whose epilogue loops).
 typedef float mtv_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void mtv_store_out4(float* p, const mtv_f32x4& v) {
+typedef unsigned mtv_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mtv_store_out4(float* base, size_t idx, const mtv_f32x4& v) {
 #if defined(MTV_OUT_PLAIN) && MTV_OUT_PLAIN
-    *reinterpret_cast<mtv_f32x4*>(p) = v;
+    *reinterpret_cast<mtv_f32x4*>(base + idx) = v;
 #else
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    float* const b = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(b, 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mtv_u32x4, v), rs, (unsigned)(idx * 4), 0, 17);      // 17 = sc0 | sc1
 #endif
 }
 #endif
