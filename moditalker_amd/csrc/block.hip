@@ -468,15 +468,18 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
         // residual share of this head: input slabs h, h + H, ... of this tile's rows / columns (requested now, used in the epilogue)
         const int nq4 = a.ncols >> 2;
         constexpr int RU = 2;                                              // 16 x 256 / 4 = 1024 quads / 512 threads
-        f32x4 rres[RU];
+        f32x4 rres[RU], rbias[RU];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             rres[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rbias[u] = rres[u];
             const int e = tid + BLK_NTH * u;
             const int rr = e / nq4, cq = e - rr * nq4;
             const int tok = q0 + rr;
             if (e < 16 * nq4 && tok < L && h < xks)
                 rres[u] = *reinterpret_cast<const f32x4*>(a.x.p + (size_t)h * a.x.slab_stride + ((size_t)b * L + tok) * a.x.C + cp * a.ncols + 4 * cq);
+            // (head 0 carries the bias: requested here too -- read in the epilogue it was a first-touch miss on the tail of the launch's slowest workgroups)
+            if (e < 16 * nq4 && tok < L && h == 0) rbias[u] = *reinterpret_cast<const f32x4*>(a.bp + cp * a.ncols + 4 * cq);
         }
         // K rows (x d^-1/4), V^T, Q (x d^-1/4 log2 e: scores in the log2 domain) -> LDS
         for (int e = tid; e < nkt * 16 * QPR; e += BLK_NTH) {
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(BLK_NTH) void k_deep_block(const DeepBlockArgs a) {
             v += rres[u];
             for (int k = h + H; k < xks; k += H)
                 v += *reinterpret_cast<const f32x4*>(a.x.p + (size_t)k * a.x.slab_stride + ((size_t)b * L + tok) * a.x.C + n);
-            if (h == 0) v += *reinterpret_cast<const f32x4*>(a.bp + n);
+            if (h == 0) v += rbias[u];
             mtv_store_out4(outp, ((size_t)b * L + tok) * C + n, v);
         }
         __syncthreads();                                                    // (LDS is reused by the next item)

@@ -508,6 +508,24 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
     }
 
     MTV_STAMP(3);
+    // sampler-step head: the sample and the noise of this thread's output quad are requested here, ahead of the cross-wave reduction
+    // (round 6: read in the epilogue they were first-touch misses on the launch's tail; the step record `stp` arrived under the K loop)
+    float dd_x[4] = {0.f, 0.f, 0.f, 0.f}, dd_nz[4] = {0.f, 0.f, 0.f, 0.f};
+    bool dd_pre = false;
+    if (dd) {
+        constexpr int QPR0 = COLS / 4;
+        const int rr = tid / QPR0, cq = tid - rr * QPR0;
+        const int tok = tok0 + rr, n = n0 + cq * 4;
+        dd_pre = tid < ROWS * QPR0 && tok < a.Lout && n < a.N;
+        if (dd_pre) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t ix = ((size_t)b * a.N + n + (n + k < a.N ? k : 0)) * a.Lout + tok;
+                dd_x[k] = ddv.x[ix];
+                dd_nz[k] = stp.noise_index >= 0 ? ddv.noise[(size_t)stp.noise_index * ddv.n_per_draw + ix] : 0.f;
+            }
+        }
+    }
     // ---- fixed-order tree over the NW waves (lane-linear LDS image: conflict-free), LDS reused
     __syncthreads();
     float* red = smem;
@@ -671,8 +689,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv(const ConvArgs a) {
             for (int k = 0; k < 4; ++k) {
                 const bool in = n + k < a.N;
                 const size_t ix = ((size_t)b * a.N + n + (in ? k : 0)) * a.Lout + tok;
-                xo[k] = ddv.x[ix];
-                nz[k] = stp.noise_index >= 0 ? ddv.noise[(size_t)stp.noise_index * ddv.n_per_draw + ix] : 0.f;
+                if (e == tid && dd_pre) {
+                    xo[k] = dd_x[k];
+                    nz[k] = dd_nz[k];
+                } else {
+                    xo[k] = ddv.x[ix];
+                    nz[k] = stp.noise_index >= 0 ? ddv.noise[(size_t)stp.noise_index * ddv.n_per_draw + ix] : 0.f;
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

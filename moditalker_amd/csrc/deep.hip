@@ -552,6 +552,11 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
     const bool pool_r = a.pool_res != 0 && a.res.p != nullptr && s < a.res.ks;
     const bool pre_ok = s == 0 && tid < QUADS && tid / QPR < rg_ntok;
     if (pre_ok) pre = epi_operands(tid);
+    // (the pooled residual of this thread's first quad: requested now as well -- where the tile leaves the registers for it)
+    const bool prep_ok = RT * NT <= 8 && pool_r && tid < QUADS && tid / QPR < rg_ntok;
+    f32x4 prep = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (RT * NT <= 8)
+        if (prep_ok) prep = pooled_res(tid);
 
     f32x4 accm[RT][NT];
 #pragma unroll
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
 #pragma unroll
         for (int w = 1; w < NIMG; ++w) v += *reinterpret_cast<const f32x4*>(rp + (size_t)w * ROWS * LDR);
         if (s == 0) v += (e == tid && pre_ok) ? pre : epi_operands(e);
-        if (pool_r) v += pooled_res(e);
+        if (pool_r) v += (e == tid && prep_ok) ? prep : pooled_res(e);
         const size_t qoff = ((size_t)b * a.Lout + rg_tok0 + rr) * a.N + n0 + 4 * cq;
         float* dst = outp + qoff;
         if (fin) deep_park_quad(dst, v);
