@@ -1578,8 +1578,21 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
     const int i = lane & 15, q = lane >> 4;
     DEEP_STAMP(0);
     const int blk = deep_usgpr((int)blockIdx.x);
-    const int cg = deep_usgpr(FDiv{a.inv_Bt}(blk, a.Bt));
-    const int brt = blk - cg * a.Bt;
+    // block -> (column group, row tile).  xmap 0: the column groups of one row tile are Bt workgroups apart -- with a multiple of 8 row tiles they share an
+    // XCD and the rows they all stage, and every XCD reads the whole weight matrix.  xmap 1 (ConvTile::XM = 1, weight-dominated shapes: the qkv convs at 128
+    // tokens re-fetched their 3.1 MB once per XCD, 25.8 MB per launch in profiles/r06_per_op_traffic.txt): workgroup id mod 8 = the XCD selects the column
+    // group (k_conv_win's xmap 1), so a column group's weights go through ONE L2 and the (smaller) rows are what the XCDs re-read.  Speed only.
+    int cg, brt;
+    if (a.xmap == 0) {
+        cg = FDiv{a.inv_Bt}(blk, a.Bt);
+        brt = blk - cg * a.Bt;
+    } else {
+        const int xcd = blk & 7, j = blk >> 3;
+        brt = FDiv{a.inv_Sx}(j, a.Sx);
+        cg = xcd + 8 * (j - brt * a.Sx);
+    }
+    cg = deep_usgpr(cg);
+    brt = deep_usgpr(brt);
     const int b = deep_usgpr(FDiv{a.inv_tiles_per_b}(brt, a.tiles_per_b));
     const int tok0 = (brt - b * a.tiles_per_b) * ROWS, n0 = cg * COLS;
     const int K = a.Cmain, SA = K + DEEP_PAD;
@@ -2197,7 +2210,7 @@ hipError_t launch_conv_win(const ConvArgs& a, ConvTile t, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-// ---- k_conv_pw (ConvTile{MT, NTW, NW = 96, KS = 1, XM = 0}) ----
+// ---- k_conv_pw (ConvTile{MT, NTW, NW = 96, KS = 1 | 6 | 4 | 2 = multiplying waves, XM}) ----
 static int conv_pw_waves(int code) { return code == 1 ? 8 : code; }      // ConvTile::KS of a k_conv_pw tile: 1 = all 8 waves multiply, else 6 / 4 / 2
 static size_t conv_pw_layout(const ConvArgs& a, int MT, int NTW, int NWA) {
     const int ROWS = 16 * MT, COLS = 16 * NTW * NWA;
@@ -2221,13 +2234,18 @@ bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW, int wcode) {
 size_t conv_pw_smem_bytes(const ConvArgs& a, ConvTile t) { return conv_pw_layout(a, t.MT, t.NT, conv_pw_waves(t.KS)); }
 
 template <int MT, int NTW, int NWA>
-static hipError_t conv_pw_launch_t(const ConvArgs& a0, hipStream_t s) {
+static hipError_t conv_pw_launch_t(const ConvArgs& a0, int xm, hipStream_t s) {
     ConvArgs a = a0;
     if (!conv_pw_eligible(a, MT, NTW, NWA == 8 ? 1 : NWA)) return hipErrorInvalidValue;
     constexpr int COLS = 16 * NTW * NWA;
     const int tiles = (a.Lout + 16 * MT - 1) / (16 * MT), groups = (a.N + COLS - 1) / COLS;
     a.KS = 1;
     a.xmap = 0;
+    if (xm && groups % 8 == 0) {                            // (a grid the XCD map does not tile keeps the plain order)
+        a.xmap = 1;
+        a.Sx = groups / 8;
+        a.inv_Sx = 1.0f / (float)a.Sx;
+    }
     a.tiles_per_b = tiles;
     a.tiles_n = groups;
     a.Bt = a.B * tiles;
@@ -2238,17 +2256,20 @@ static hipError_t conv_pw_launch_t(const ConvArgs& a0, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_conv_pw(const ConvArgs& a, ConvTile t, hipStream_t s) {
+    static const int env_xm = getenv("MTV_PW_XM") ? atoi(getenv("MTV_PW_XM")) : -1;         // (A/B hook: block order of every k_conv_pw launch)
+    int xm = env_xm >= 0 ? env_xm : t.XM;
+    if (xm == 2) xm = (long)a.N >= 2L * a.B * a.Lout;                                       // (hook value 2: only where the weights are twice the rows)
     const int nwa = conv_pw_waves(t.KS);
-    if (t.MT == 1 && t.NT == 1 && nwa == 8) return conv_pw_launch_t<1, 1, 8>(a, s);
-    if (t.MT == 1 && t.NT == 2 && nwa == 8) return conv_pw_launch_t<1, 2, 8>(a, s);
-    if (t.MT == 2 && t.NT == 1 && nwa == 8) return conv_pw_launch_t<2, 1, 8>(a, s);
-    if (t.MT == 2 && t.NT == 2 && nwa == 8) return conv_pw_launch_t<2, 2, 8>(a, s);
-    if (t.MT == 1 && t.NT == 1 && nwa == 6) return conv_pw_launch_t<1, 1, 6>(a, s);
-    if (t.MT == 2 && t.NT == 1 && nwa == 6) return conv_pw_launch_t<2, 1, 6>(a, s);
-    if (t.MT == 1 && t.NT == 1 && nwa == 4) return conv_pw_launch_t<1, 1, 4>(a, s);
-    if (t.MT == 2 && t.NT == 1 && nwa == 4) return conv_pw_launch_t<2, 1, 4>(a, s);
-    if (t.MT == 1 && t.NT == 1 && nwa == 2) return conv_pw_launch_t<1, 1, 2>(a, s);
-    if (t.MT == 2 && t.NT == 1 && nwa == 2) return conv_pw_launch_t<2, 1, 2>(a, s);
+    if (t.MT == 1 && t.NT == 1 && nwa == 8) return conv_pw_launch_t<1, 1, 8>(a, xm, s);
+    if (t.MT == 1 && t.NT == 2 && nwa == 8) return conv_pw_launch_t<1, 2, 8>(a, xm, s);
+    if (t.MT == 2 && t.NT == 1 && nwa == 8) return conv_pw_launch_t<2, 1, 8>(a, xm, s);
+    if (t.MT == 2 && t.NT == 2 && nwa == 8) return conv_pw_launch_t<2, 2, 8>(a, xm, s);
+    if (t.MT == 1 && t.NT == 1 && nwa == 6) return conv_pw_launch_t<1, 1, 6>(a, xm, s);
+    if (t.MT == 2 && t.NT == 1 && nwa == 6) return conv_pw_launch_t<2, 1, 6>(a, xm, s);
+    if (t.MT == 1 && t.NT == 1 && nwa == 4) return conv_pw_launch_t<1, 1, 4>(a, xm, s);
+    if (t.MT == 2 && t.NT == 1 && nwa == 4) return conv_pw_launch_t<2, 1, 4>(a, xm, s);
+    if (t.MT == 1 && t.NT == 1 && nwa == 2) return conv_pw_launch_t<1, 1, 2>(a, xm, s);
+    if (t.MT == 2 && t.NT == 1 && nwa == 2) return conv_pw_launch_t<2, 1, 2>(a, xm, s);
     return hipErrorInvalidValue;
 }
 

@@ -1306,7 +1306,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
             const bool lin_ok = t.NW == 64 && (t.MT == 1 || t.MT == 2) && (t.NT == 1 || t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && t.XM == 0 && conv_lin_eligible(a);
             const bool b3_ok = t.NW == 48 && !(a.B == 1 && a.Lout <= 2048) && x3_tile_exists(t.MT, t.NT) && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 8) && t.XM == 0 && t.KS * 6 <= a.ntaps * (a.Cmain / 32) + a.Cskip / 32 && conv_x3_eligible(a) && a.x3 && conv_x3_smem_bytes(a, t) <= CONV_X3_MAX_LDS;
             const bool win_ok = t.NW == 80 && (t.MT == 1 || t.MT == 2) && (t.NT == 2 || t.NT == 4) && (t.KS == 1 || t.KS == 2 || t.KS == 4) && (t.XM == 0 || t.XM == 1) && conv_win_eligible(a, t.MT, t.NT, t.KS);
-            const bool pw_ok = t.NW == 96 && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 6) && t.XM == 0 && conv_pw_eligible(a, t.MT, t.NT, t.KS);
+            const bool pw_ok = t.NW == 96 && (t.KS == 1 || t.KS == 2 || t.KS == 4 || t.KS == 6) && (t.XM == 0 || t.XM == 1) && conv_pw_eligible(a, t.MT, t.NT, t.KS);
             const bool shape_ok = tiled_ok || lin_ok || b3_ok || win_ok || pw_ok ||
                                   ((t.MT == 1 || t.MT == 2 || t.MT == 4) && (t.NT == 1 || t.NT == 2 || t.NT == 4) &&
                                    (t.NW == 1 || t.NW == 2 || t.NW == 4 || t.NW == 8 || t.NW == 16) && !(t.NW == 16 && t.MT * t.NT >= 8) &&
@@ -1459,11 +1459,15 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                 for (int MT = 1; MT <= 2; ++MT)
                     for (int NTW = 1; NTW <= 2; ++NTW)
                       for (int wc : {1, 6, 4, 2}) {
+                      for (int XM = 0; XM < 2; ++XM) {
                         if (!conv_pw_eligible(a, MT, NTW, wc)) continue;
-                        const ConvTile t{MT, NTW, 96, wc, 0};
+                        const ConvTile t{MT, NTW, 96, wc, XM};
                         const int cols = 16 * NTW * (wc == 1 ? 8 : wc);
                         if (wc != 1 && a.N % cols) continue;                 // (narrower column tiles only where they divide N: whole tiles, a full grid)
                         if ((long)a.B * ((a.Lout + 16 * MT - 1) / (16 * MT)) * ((a.N + cols - 1) / cols) < 48) continue;
+                        // (the XCD-aware block order only where the column groups tile the 8 XCDs and the weights dwarf the rows: measured -0.5 ... -0.8 us per
+                        // launch at [128 x 1536, K = 512], +0.3 ... +0.8 at 512 tokens -- profiles/r06_conv_pw_xcd_order_ab.txt)
+                        if (XM == 1 && (((a.N + cols - 1) / cols) % 8 || (long)a.N < 8L * a.B * a.Lout)) continue;
                         float samp[16];
                         HIPCHK(run(t));
                         for (int w = 0; w < nsamp; ++w) {
@@ -1479,6 +1483,7 @@ int autotune(mtv_ctx* c, Plan* p, hipStream_t s) {
                             best_ms = samp[nsamp / 2];
                             best = t;
                         }
+                      }
                     }
             }
             // the lean 1x1 kernel (lin.hip): wave tile 16 MT x 16 NT, NWV waves side by side along N, whole K per wave

@@ -236,8 +236,12 @@ def test_committed_tile_table_is_well_formed():
             Ls, Lk = int(m.group(3)), int(m.group(4))
             assert xm == (1 if (taps * Cm + Cs) * N >= B * (Ls * Cm + Lk * Cs + L * N) else 0), line
         elif nw == 96:                    # k_conv_pw<MT, NTW, NWA> (csrc/deep.hip): 1x1 on identity rows, whole K per wave; KS = multiplying waves (1 = all 8)
-            assert taps == 1 and mt in (1, 2) and nt in (1, 2) and xm == 0 and N % (16 * nt) == 0 and Cs == 0 and 64 <= Cm <= 512, line
+            assert taps == 1 and mt in (1, 2) and nt in (1, 2) and N % (16 * nt) == 0 and Cs == 0 and 64 <= Cm <= 512, line
             assert ks == 1 or (nt == 1 and ks in (2, 4, 6) and N % (16 * ks) == 0), line       # narrower column tiles only where they divide N
+            # XM (round 6): a column group's weights through ONE XCD's L2 -- only where the column groups tile the 8 XCDs and the weights
+            # dwarf the rows (measured: it pays at 128 tokens x 1536 columns, costs 0.3-0.8 us per launch at 512 tokens)
+            groups = N // (16 * nt * (8 if ks == 1 else ks))
+            assert xm == (1 if groups % 8 == 0 and N >= 8 * B * L else 0), line
         elif nw == 32:                    # k_conv_lds<WM, WN>
             assert mt in (2, 4) and nt in (2, 4, 8) and ks == 1, line
         else:                             # k_conv<MT, NT, NW>
