@@ -293,8 +293,20 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_conv(const DeepArgs a) {
     // XCDs) share the column tile and differ in (b, rg, s): all column tiles of one (rg, s) -- which read the SAME activation
     // slice -- meet on one XCD when nslots is a multiple of 8 (speed only).
     const int blk = deep_usgpr((int)blockIdx.x);
-    const int j = deep_usgpr(FDiv{a.inv_nslots}(blk, a.nslots));
-    const int slot = blk - j * a.nslots;
+    int j, slot;
+    if (a.xm) {
+        // (weight-dominated convs at 128 tokens: the row groups {xy} | {yt, xt} of a (K slice, column tile) read the same weight run from two XCDs -- 2 x the weights
+        // through the fabric, profiles/r06_per_op_traffic.txt.  Here the XCD = (K slice, low bits of the column tile) and both row groups sit on it; an activation
+        // slice is then read by 8 / KS XCDs instead of one.  Speed only.)
+        const int xcd = blk & 7, idx = blk >> 3;
+        j = ((idx >> 1) << a.xm_jbits) + (xcd >> a.ks_shift);
+        slot = ((idx & 1) << a.ks_shift) + (xcd & (a.KS - 1));
+    } else {
+        j = FDiv{a.inv_nslots}(blk, a.nslots);
+        slot = blk - j * a.nslots;
+    }
+    j = deep_usgpr(j);
+    slot = deep_usgpr(slot);
     const int s = slot & (a.KS - 1);
     const int rgb = slot >> a.ks_shift;
     const int rg = rgb & (a.nrg - 1);
@@ -2005,6 +2017,15 @@ hipError_t launch_deep_conv(const DeepArgs& a0, DeepTile t, hipStream_t s) {
     a.nch = a.nmain_ch + (a.Cskip ? a.CSs / 16 : 0);
     a.nslots = a.B * a.nrg * a.KS;
     a.inv_nslots = 1.0f / (float)a.nslots;
+    a.xm = 0;
+    a.xm_jbits = 0;
+    {
+        static const int env_xm = getenv("MTV_DEEP_XM") ? atoi(getenv("MTV_DEEP_XM")) : 1;       // (A/B hook: 0 = the plain order everywhere)
+        if (env_xm && a.B == 1 && a.nrg == 2 && a.KS <= 8 && a.tiles_n % (8 >> a.ks_shift) == 0) {
+            a.xm = 1;
+            a.xm_jbits = 3 - a.ks_shift;
+        }
+    }
     a.inv_r = 1.0f / (float)a.r;
     a.inv_rs = 0.f;
     {   // reciprocal element counts of the GroupNorm statistics (source level): planes 0, 1, 2 and all planes together

@@ -345,6 +345,8 @@ struct DeepArgs {
     int ks_shift, cpt_shift; // log2(KS), log2(CSm / 16)
     int nmain_ch, nch;       // 16-channel chunks per slice: ntaps * CSm / 16, + CSs / 16
     int nslots;              // B * nrg * KS
+    int xm, xm_jbits;        // xm = 1 (B = 1, nrg = 2): workgroup id mod 8 = the XCD selects (K slice, low xm_jbits bits of the column tile), so the two row groups of a (K slice,
+                             // column tile) -- which stream the SAME weights -- meet on one XCD
     float inv_nslots, inv_r, inv_rs;
     int lds_skip, lds_idx, lds_stat, lds_red;   // LDS offsets (floats): skip slice | row table | statistics scratch | reduction scratch
     int src_rows_max;        // rows of the staged main slice (largest row group) -- its zero row follows
