@@ -1192,10 +1192,14 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_win(const ConvArgs a) {
         const int xcd = blk & 7, j = blk >> 3;
         brt = FDiv{a.inv_Sx}(j, a.Sx);
         ct = xcd + 8 * (j - brt * a.Sx);
-    } else {
+    } else if (a.xmap == 2) {
         const int xcd = blk & 7, j = blk >> 3;
         ct = xcd & ((1 << a.Sx) - 1);
         brt = (j << (3 - a.Sx)) + (xcd >> a.Sx);
+    } else {                                               // xmap 3: XCD x owns the row tiles [x Sx, (x + 1) Sx) -- a contiguous eighth of the tokens, whatever the tile height
+        const int xcd = blk & 7, j = blk >> 3;
+        ct = FDiv{a.inv_Sx}(j, a.Sx);
+        brt = xcd * a.Sx + (j - ct * a.Sx);
     }
     ct = deep_usgpr(ct);
     brt = deep_usgpr(brt);
@@ -1598,10 +1602,14 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
     if (a.xmap == 0) {
         cg = FDiv{a.inv_Bt}(blk, a.Bt);
         brt = blk - cg * a.Bt;
-    } else {
+    } else if (a.xmap == 1) {
         const int xcd = blk & 7, j = blk >> 3;
         brt = FDiv{a.inv_Sx}(j, a.Sx);
         cg = xcd + 8 * (j - brt * a.Sx);
+    } else {                                               // xmap 3: XCD x owns the row tiles [x Sx, (x + 1) Sx) (k_conv_win's xmap 3)
+        const int xcd = blk & 7, j = blk >> 3;
+        cg = FDiv{a.inv_Sx}(j, a.Sx);
+        brt = xcd * a.Sx + (j - cg * a.Sx);
     }
     cg = deep_usgpr(cg);
     brt = deep_usgpr(brt);
@@ -1644,17 +1652,21 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
             }
     }
     // weights: wave w owns the NTW column blocks of 16 that start at n0 + 16 NTW w; lane (j, q) holds, of column block nb, output
-    // channel nw0 + NTW j + nb (its NTW channels are consecutive: 4 NTW-float runs per lane in the LDS image below)
+    // channel nw0 + 16 nb + j
     const int nw0 = n0 + 16 * NTW * wave;
     const bool wave_on = wave < NWA && nw0 < a.N;          // (N is a multiple of 16 NTW: a wave is all in or all out)
     const int nch = K >> 4;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wnk), 0, a.N * K * 4, 0x00020000);
-    const int wlane = ((nw0 + NTW * i) * K + 4 * q) * 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wpk), 0, a.N * K * 4, 0x00020000);
+    // (round 6: the weights come lane-linear -- ConvArgs::Wpk, [N / 16][K / 16][64 lanes][4] -- so a wave's B fragment of a chunk is ONE contiguous KB.  Read from the
+    // checkpoint's [N][K] rows, lane (j, q) fetched 16 bytes of row j: the 16 lanes of a quarter-wave hit 16 different lines and every line was touched by four
+    // quarter-waves -- 64 tag look-ups per instruction instead of 16, and the 8 ... 16 weight requests of a wave stood in front of the K loop for ~50-100 cycles each:
+    // profiles/r06_conv_pw_packed_weights.txt)
+    const int wlane = ((nw0 >> 4) * nch * 64 + lane) * 16;
     f32x4 bq[2][G][NTW];
     auto wload1 = [&](f32x4 (&dstg)[NTW], int c) {
-        const int soff = (c < nch && wave_on) ? c * 64 : 0x7F000000;      // (past the end: out of range = zeros)
+        const int soff = (c < nch && wave_on) ? c * 1024 : 0x7F000000;      // (past the end: out of range = zeros)
 #pragma unroll
-        for (int nb = 0; nb < NTW; ++nb) dstg[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + nb * K * 4, soff, 0));
+        for (int nb = 0; nb < NTW; ++nb) dstg[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + nb * nch * 1024, soff, 0));
     };
     auto wload = [&](f32x4 (&dst)[G][NTW], int c0) {
 #pragma unroll
@@ -1804,13 +1816,13 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
     constexpr int LDR = COLS + 4;
     float* const red = smem;
     if (wave_on) {
-        float* my = red + (4 * q) * LDR + 16 * NTW * wave + NTW * i;
+        float* my = red + (4 * q) * LDR + 16 * NTW * wave + i;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                for (int nb = 0; nb < NTW; ++nb) my[(16 * mt + rr) * LDR + nb] = acc[mt][nb][rr];
+                for (int nb = 0; nb < NTW; ++nb) my[(16 * mt + rr) * LDR + 16 * nb] = acc[mt][nb][rr];
     }
     float* scratch = red + ROWS * LDR;
     {
@@ -2205,6 +2217,14 @@ static hipError_t conv_win_launch_t(const ConvArgs& a0, int xm, int KS, hipStrea
     a.tiles_per_b = tiles;
     a.tiles_n = tiles_n;
     a.Bt = a.B * tiles;
+    {
+        static const int env_rb = getenv("MTV_ROW_BLOCKED") ? atoi(getenv("MTV_ROW_BLOCKED")) : 0;       // (A/B hook)
+        if (env_rb && a.xmap == 0 && a.Bt % 8 == 0) {
+            a.xmap = 3;
+            a.Sx = a.Bt / 8;
+            a.inv_Sx = 1.0f / (float)a.Sx;
+        }
+    }
     a.inv_tiles_per_b = 1.0f / (float)tiles;
     a.inv_Bt = 1.0f / (float)a.Bt;
     a.cps_q = a.Cskip / KS;                                  // skip / tapped channels of a K slice; the kernel's chunk walk is per slice:
@@ -2243,7 +2263,7 @@ bool conv_pw_eligible(const ConvArgs& a, int MT, int NTW, int wcode) {
     const int NWA = conv_pw_waves(wcode);
     if (!((MT == 1 || MT == 2) && (NTW == 1 || NTW == 2))) return false;       // (NTW = 3 measured slower than 1 and 2 on every shape: not built)
     if (!(NWA == 8 || (NTW == 1 && (NWA == 6 || NWA == 4 || NWA == 2)))) return false;
-    if (!a.Wnk || a.ntaps != 1 || a.nmain != 1 || a.nskip != 0 || a.Cskip != 0 || a.gather || a.gather_skip || a.geo_main || a.geo_skip) return false;
+    if (!a.Wpk || (a.N & 15) || a.ntaps != 1 || a.nmain != 1 || a.nskip != 0 || a.Cskip != 0 || a.gather || a.gather_skip || a.geo_main || a.geo_skip) return false;
     if (a.out_cm || a.ddim || a.bias_b || a.bias2) return false;
     if ((a.Cmain & 15) || a.Cmain < 64 || a.Cmain > 512 || (512 % (a.Cmain >> 2)) || a.N % (16 * NTW) || a.Lsrc != a.Lout || (a.res && a.Lskip != a.Lout)) return false;
     if (16 * MT > 8 * (512 / (a.Cmain >> 2)) * 2) return false;              // (rows beyond the first pass are fetched late: keep that to one extra pass)
@@ -2270,6 +2290,14 @@ static hipError_t conv_pw_launch_t(const ConvArgs& a0, int xm, hipStream_t s) {
     a.tiles_per_b = tiles;
     a.tiles_n = groups;
     a.Bt = a.B * tiles;
+    {
+        static const int env_rb = getenv("MTV_ROW_BLOCKED") ? atoi(getenv("MTV_ROW_BLOCKED")) : 0;       // (A/B hook)
+        if (env_rb && a.xmap == 0 && a.Bt % 8 == 0) {
+            a.xmap = 3;
+            a.Sx = a.Bt / 8;
+            a.inv_Sx = 1.0f / (float)a.Sx;
+        }
+    }
     a.inv_tiles_per_b = 1.0f / (float)tiles;
     a.inv_Bt = 1.0f / (float)a.Bt;
     if ((long)a.Bt * groups >= (1L << 21)) return hipErrorInvalidValue;

@@ -945,6 +945,24 @@ __global__ void k_repack_conv(const float* src, float* dst, int N, int C, int nt
     dst[((size_t)tap * C + c) * ld + n] = src[((size_t)n * C + c) * ntaps + tap];
 }
 
+// [N][C] (the checkpoint's layout of a 1x1 conv) -> [N / 16][C / 16][64 lanes][4] (ConvArgs::Wpk): one thread per 16-byte quad of the destination
+__global__ void k_repack_pw(const float* src, float* dst, int N, int C) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = C >> 4;
+    if (idx >= (long)(N >> 4) * nch * 64) return;
+    const int lane = (int)(idx & 63);
+    const long bc = idx >> 6;
+    const int c = (int)(bc % nch), bn = (int)(bc / nch);
+    const int j = lane & 15, q = lane >> 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(16 * bn + j) * C + 16 * c + 4 * q);
+    *reinterpret_cast<float4*>(dst + idx * 4) = v;
+}
+hipError_t launch_repack_pw(const float* src, float* dst, int N, int C, hipStream_t s) {
+    if ((N & 15) || (C & 15)) return hipErrorInvalidValue;
+    const long n = (long)(N >> 4) * (C >> 4) * 64;
+    hipLaunchKernelGGL(k_repack_pw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, N, C);
+    return hipGetLastError();
+}
 hipError_t launch_repack_conv(const float* src, float* dst, int N, int C, int ntaps, int ld, hipStream_t s) {
     const long n = (long)N * C * ntaps;
     hipLaunchKernelGGL(k_repack_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, N, C, ntaps, ld);

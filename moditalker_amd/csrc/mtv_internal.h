@@ -77,6 +77,8 @@ struct ConvArgs {
     int B;
     const float* W;          // rows [ntaps*Cmain + Cskip][ldw], columns = output channels
     const float* Wnk;        // 1x1 convs on identity rows only: the same weight as stored in the checkpoint, [N][Cmain] (k_lin, lin.hip)
+    const float* Wpk;        // 1x1 convs on identity rows only (N, Cmain multiples of 16): k_conv_pw's operand [N / 16][Cmain / 16][64 lanes][4] -- lane (j, q) of (column
+                             // block bn, chunk c) holds W[16 bn + j][16 c + 4 q .. + 3], so a wave's B fragment of a chunk is ONE contiguous KB (k_repack_pw, kernels.hip)
     const void* W3;          // the same matrix as three bf16 planes [3][K/8][ldw][8] with W = W0 + W1 + W2 (k_conv_x3, conv_x3.hip) or nullptr
     unsigned long long w3_plane;   // bytes between the planes
     void* x3;                // scratch for this conv's split activations (k_x3_prep -> k_conv_x3, conv_x3.hip) or nullptr
@@ -523,6 +525,7 @@ hipError_t launch_step_sinusoid(const DdimStep* steps, int n_steps, const float*
 hipError_t launch_linear_rows(const LinearArgs& a, hipStream_t s);   // k_linear for many rows: W read once per 8 rows
 hipError_t launch_ddim_init(const DdimFuse* f, hipStream_t s);
 hipError_t launch_repack_conv(const float* src, float* dst, int N, int C, int ntaps, int ld, hipStream_t s);
+hipError_t launch_repack_pw(const float* src, float* dst, int N, int C, hipStream_t s);      // [N][C] -> ConvArgs::Wpk layout
 // ---- autoencoder kernels (ae.hip) ----
 hipError_t launch_repack_qkv(const float* src, float* dst, int H, int d, int C, int ld, hipStream_t s);
 hipError_t launch_repeat(const float* src, float* dst, int n, int rep, hipStream_t s);

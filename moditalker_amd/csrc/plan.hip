@@ -769,12 +769,16 @@ struct Builder {
         wconv(P + "qkv.weight", 3 * C, C, 1, 1, true, Wq, ldq);
         float* Wq_nk = c->buf("wnk." + P + "qkv.weight", (size_t)3 * C * C);      // the same weights as stored, [3C][C]: k_lin's operand
         c->slots[c->slot_index[P + "qkv.weight"]].dst2 = Wq_nk;
+        float* Wq_pk = (C & 15) ? nullptr : c->buf("wpk." + P + "qkv.weight", (size_t)3 * C * C);      // ... and lane-linear: k_conv_pw's operand
+        c->slots[c->slot_index[P + "qkv.weight"]].dst3 = Wq_pk;
         float* bq = c->wcopy(P + "qkv.bias", {3 * C});
         const int ldp = pad64(C);
         float* Wp = c->buf("w." + P + "proj_out.weight", (size_t)C * ldp);
         wconv(P + "proj_out.weight", C, C, 1, 1, true, Wp, ldp);
         float* Wp_nk = c->buf("wnk." + P + "proj_out.weight", (size_t)C * C);
         c->slots[c->slot_index[P + "proj_out.weight"]].dst2 = Wp_nk;
+        float* Wp_pk = (C & 15) ? nullptr : c->buf("wpk." + P + "proj_out.weight", (size_t)C * C);
+        c->slots[c->slot_index[P + "proj_out.weight"]].dst3 = Wp_pk;
         float* bp = c->wcopy(P + "proj_out.bias", {C});
 
         // ---- deep level (deep.hip): attention core + proj_out in ONE launch (k_deep_attn; the head groups are the K slices of the
@@ -931,7 +935,7 @@ struct Builder {
         add_stats({x}, lvl, site);
         float* qkv = c->act(nm + ".qkv", lvl, 3 * C);
         ConvArgs a{};
-        a.ntaps = 1; a.Lout = L.L; a.Lsrc = L.L; a.N = 3 * C; a.W = Wq; a.Wnk = Wq_nk; a.ldw = ldq; a.bias = bq; a.out = qkv;
+        a.ntaps = 1; a.Lout = L.L; a.Lsrc = L.L; a.N = 3 * C; a.W = Wq; a.Wnk = Wq_nk; a.Wpk = Wq_pk; a.ldw = ldq; a.bias = bq; a.out = qkv;
         a.nmain = 1; a.src[0] = x.p; a.C[0] = C; a.Cmain = C; a.seg_src = L.seg();
         a.gn = GnIn{site, gw, gb, nullptr, 0, C / 32, whole ? 1 : 0, 0, (unsigned)c->stats_copy_doubles};
         add_conv(a, nm + ".qkv", lvl);
@@ -943,7 +947,7 @@ struct Builder {
         Tens out;
         out.lvl = lvl; out.C = C; out.p = c->act(nm + ".out", lvl, C);
         ConvArgs p{};
-        p.ntaps = 1; p.Lout = L.L; p.Lsrc = L.L; p.Lskip = L.L; p.N = C; p.W = Wp; p.Wnk = Wp_nk; p.ldw = ldp; p.bias = bp; p.out = out.p;
+        p.ntaps = 1; p.Lout = L.L; p.Lsrc = L.L; p.Lskip = L.L; p.N = C; p.W = Wp; p.Wnk = Wp_nk; p.Wpk = Wp_pk; p.ldw = ldp; p.bias = bp; p.out = out.p;
         p.nmain = 1; p.src[0] = att; p.C[0] = C; p.Cmain = C; p.seg_src = L.seg();
         p.res = x.p;
         add_conv(p, nm + ".proj", lvl);
@@ -1752,6 +1756,7 @@ int mtv_load_weight(mtv_ctx* c, const char* key, const float* data, int ndim, co
         const int ntaps = (int)(n / ((size_t)N * C));
         HIPCHK(launch_repack_conv(c->staging, s.dst, N, C, ntaps, s.ld, nullptr));
         if (s.dst2) HIPCHK(hipMemcpyAsync(s.dst2, c->staging, n * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+        if (s.dst3) HIPCHK(launch_repack_pw(c->staging, s.dst3, N, C, nullptr));
         HIPCHK(hipStreamSynchronize(nullptr));
     }
     s.loaded = true;

@@ -50,6 +50,7 @@ struct WSlot {
     bool loaded;
     int aux = 0;    // ROLE_QKV_HEADS: head dim; ROLE_REPEAT: repeat count
     float* dst2 = nullptr;   // ROLE_CONV, 1x1 only: a second copy in the checkpoint's own layout [N][C] (k_lin, lin.hip)
+    float* dst3 = nullptr;   // ROLE_CONV, 1x1 only, N and C multiples of 16: a third copy in k_conv_pw's lane-linear layout (ConvArgs::Wpk)
 };
 
 struct Tens {

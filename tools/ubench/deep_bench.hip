@@ -758,6 +758,12 @@ static void do_pw(int r, int t, int K, int N) {
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) { const float v = frand() * wsc; W[(size_t)k * ldw + n] = v; Wnk[(size_t)n * K + k] = v; }
     float *gamma = dup(ones), *beta = dup(zeros), *bias = dup(zeros), *dW = dup(W), *dWnk = dup(Wnk), *dx = dup(x);
+    std::vector<float> Wpk((size_t)N * K);                             // k_conv_pw's lane-linear copy (ConvArgs::Wpk; the product: k_repack_pw)
+    for (int bn = 0; bn < N / 16; ++bn)
+        for (int c = 0; c < K / 16; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) Wpk[(((size_t)bn * (K / 16) + c) * 64 + lane) * 4 + e] = Wnk[(size_t)(16 * bn + (lane & 15)) * K + 16 * c + 4 * (lane >> 4) + e];
+    float* dWpk = dup(Wpk);
     float* dy = dnew<float>((size_t)L * N);
     hipStream_t s;
     CK(hipStreamCreate(&s));
@@ -775,7 +781,7 @@ static void do_pw(int r, int t, int K, int N) {
     }
     ConvArgs a{};
     a.src[0] = dx; a.C[0] = K; a.nmain = 1; a.Cmain = K; a.ntaps = 1; a.Lout = L; a.Lsrc = L; a.Lskip = L; a.B = 1;
-    a.W = dW; a.Wnk = dWnk; a.ldw = ldw; a.N = N; a.bias = bias; a.out = dy;
+    a.W = dW; a.Wnk = dWnk; a.Wpk = dWpk; a.ldw = ldw; a.N = N; a.bias = bias; a.out = dy;
     a.seg_src = SegInfo{b1, b2, L}; a.seg_out = a.seg_src; a.slab = slab; a.tickets = tickets;
     a.gn = GnIn{sites, gamma, beta, nullptr, 0, K / 32, 0, 0, 192};
     a.gn.inv_gs = 1.0f / (K / 32);
