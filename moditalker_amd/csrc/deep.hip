@@ -1757,6 +1757,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
                 else *reinterpret_cast<f32x4*>(lA + row * SA + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
             }
     }
+    DEEP_STAMP(10);
     // epilogue operands of this thread's first output quad: requested before the K loop's barrier (a round trip off the tail)
     constexpr int QPR = COLS / 4, NQ = ROWS * QPR, EPT = (NQ + DEEP_NTH - 1) / DEEP_NTH;
     // (the bias too -- round 6: read inside the epilogue loop it was a first-touch miss on the launch's tail: every kernel starts on invalidated caches)
@@ -1772,6 +1773,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_conv_pw(const ConvArgs a) {
             if (a.res) e_res[u] = *reinterpret_cast<const f32x4*>(a.res + ((size_t)b * a.Lskip + tok0 + rr) * a.N + n0 + 4 * cq);
         }
     }
+    DEEP_STAMP(11);
     __syncthreads();
     DEEP_STAMP(5);
     // ---- K loop: a wave multiplies the whole K for its 16 NTW columns; A fragments from the parked rows

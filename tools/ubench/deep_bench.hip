@@ -816,8 +816,8 @@ static void do_pw(int r, int t, int K, int N) {
         if (tile.NW == 96) {
             unsigned long long h[64];
             CK(hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
-            static const char* nm[10] = {"entry", "decoded", "requests issued", "stats barrier", "stats2", "rows parked", "mfma done", "image", "-", "end"};
-            static const int order[] = {1, 2, 3, 4, 5, 6, 7, 9, -1};
+            static const char* nm[12] = {"entry", "decoded", "requests issued", "stats barrier", "stats2", "rows parked", "mfma done", "image", "-", "end", "transformed", "epilogue operands requested"};
+            static const int order[] = {1, 2, 3, 4, 10, 11, 5, 6, 7, 9, -1};
             for (int blk = 0; blk < 2; ++blk)
                 for (int role = 0; role < 2; ++role) {
                     printf("    stamps wg %s %s:", blk ? "mid" : "0", role ? "wave 4" : "wave 0");
