@@ -813,7 +813,7 @@ __device__ __forceinline__ float deep_swap_max32(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-// 512 threads = 8 waves = 2 query tiles (16 queries) x 4 key parts.  Per head of the group: K rows, V^T and Q go to LDS (q and k
+// 512 threads = 8 waves = QT query tiles (16 queries) x 8 / QT key parts (DeepAttnArgs::QT: 1 since round 6, 2 before).  Per head of the group: K rows, V^T and Q go to LDS (q and k
 // scaled by d^-1/4, q also by log2 e: scores in the log2 domain), each wave computes S^T = K Q^T for its key tiles (a query is a
 // lane COLUMN: softmax reductions are register values + two lane swaps; the P^T registers are the B operand of
 // O^T += V^T P^T, as in k_attention), the four key parts of a query tile are merged through LDS into the normalised output
@@ -835,7 +835,8 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     const int hg = slot % a.nhg;
     const int rest = slot / a.nhg;
     const int qg = rest % a.nqg, b = rest / a.nqg;
-    const int q0 = qg * 32;
+    const int QT = deep_usgpr(a.QT), QR = 16 * QT;            // query tiles / query rows of this workgroup
+    const int q0 = qg * QR;
     const int L = a.L, C = a.C, HPW = a.HPW, NC = a.NC;
     // tagged completion over the head groups (DeepFin::tagged): entry ticket -> the launch's epoch
     const bool tg = a.fin.out != nullptr && a.fin.tagged != 0;
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     // keys this query group can see: all (whole) or the planes its queries live in
     int k0 = 0, k1 = L;
     if (!a.whole) {
-        const int qlast = (q0 + 32 < L ? q0 + 32 : L) - 1;
+        const int qlast = (q0 + QR < L ? q0 + QR : L) - 1;
         k0 = q0 >= b2 ? b2 : (q0 >= b1 ? b1 : 0);
         k1 = qlast >= b2 ? L : (qlast >= b1 ? b2 : b1);
     }
@@ -853,23 +854,26 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     const int VSTR = a.kcap + 4, AS = HPW * D + 8, WS = HPW * D + 4;
     float* const Ks = smem;                                   // [kcap][KSTR]
     float* const Vt = Ks + a.kcap * KSTR;                     // [D][VSTR]
-    float* const Qs = Vt + D * VSTR;                          // [32][KSTR]
-    float* const Att = Qs + 32 * KSTR;                        // [32][AS]: normalised attention rows of the head group
-    float* const Wt = Att + 32 * AS;                          // [NC][WS]: proj slice, transposed (k contiguous)
+    float* const Qs = Vt + D * VSTR;                          // [QR][KSTR]
+    float* const Att = Qs + QR * KSTR;                        // [QR][AS]: normalised attention rows of the head group
+    float* const Wt = Att + QR * AS;                          // [NC][WS]: proj slice, transposed (k contiguous)
     float* const Os = Wt + NC * WS;                           // [8 waves][16 queries][D + 4]: key-part partials (then proj partials)
     constexpr int OSF = 8 * 16 * (D + 4) > 8 * 16 * 20 + DEEP_FIN_FLOATS ? 8 * 16 * (D + 4) : 8 * 16 * 20 + DEEP_FIN_FLOATS;
     float* const ml = Os + OSF;                               // [8 waves][16 queries][2]: (m, l) of the key parts
-    const int qt = wave & 1, kp = wave >> 1;                  // this wave: query tile, key part
+    const int qt = QT == 2 ? (wave & 1) : 0, kp = QT == 2 ? (wave >> 1) : wave;      // this wave: query tile, key part
+    const int KPS = 8 / QT;                                   // key parts (= the stride of a wave's key tiles)
     // ---- proj slice requested first: it depends on nothing (held in registers until the first barrier)
     const int kw = HPW * D, wq = NC >> 2;                     // K rows of the slice, column quads
-    f32x4 wreg[2];
+    f32x4 wreg[4];                                            // (NC = 64: up to four quads per thread)
+    const int wu_n = (kw * wq + DEEP_NTH - 1) / DEEP_NTH;     // (uniform)
     {
         const float* wb = a.Wp + (size_t)(hg * kw) * a.ldw + cg * NC;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int e = tid + DEEP_NTH * u;
             const int kr = e / wq, cq = e - kr * wq;
-            wreg[u] = *reinterpret_cast<const f32x4*>(wb + (size_t)(kr < kw ? kr : 0) * a.ldw + 4 * cq);
+            if (u < 2 || u < wu_n) wreg[u] = *reinterpret_cast<const f32x4*>(wb + (size_t)(kr < kw ? kr : 0) * a.ldw + 4 * cq);
+            else wreg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     // epilogue operands of head group 0 (bias + the block's input as residual): requested now, they land under the attention
@@ -877,7 +881,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     const int nq4 = NC >> 2;
     // (RAW registers, added up in the epilogue: using a loaded value here would make the wave wait before it requests K / V)
     f32x4 pre_b = {0.f, 0.f, 0.f, 0.f}, pre_r = {0.f, 0.f, 0.f, 0.f};
-    const bool pre_ok = hg == 0 && tid < 32 * nq4 && q0 + tid / nq4 < L;
+    const bool pre_ok = hg == 0 && tid < QR * nq4 && q0 + tid / nq4 < L;
     if (pre_ok) {
         const int rr = tid / nq4, n = cg * NC + 4 * (tid - rr * nq4);
         pre_b = *reinterpret_cast<const f32x4*>(a.bias + n);
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
             kreg[u] = *reinterpret_cast<const f32x4*>(p);
             vreg[u] = *reinterpret_cast<const f32x4*>(p + D);
         }
-        if (tid < 32 * QPR) {
+        if (tid < QR * QPR) {
             const int qr = tid / QPR, qd = tid - qr * QPR;
             const int tok = q0 + qr;
             qregl = *reinterpret_cast<const f32x4*>(base + (size_t)(tok < L ? tok : 0) * 3 * C + 4 * qd);
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
                 for (int c = 0; c < 4; ++c) Vt[(4 * qd + c) * VSTR + key] = in ? vreg[u][c] : 0.f;
             }
         }
-        if (tid < 32 * QPR) {
+        if (tid < QR * QPR) {
             const int qr = tid / QPR, qd = tid - qr * QPR;
             *reinterpret_cast<f32x4*>(Qs + qr * KSTR + 4 * qd) = qregl * (a.scale * LOG2E);
         }
@@ -931,10 +935,10 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         if (hh + 1 < HPW) issue(hh + 1);
         if (hh == 0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int e = tid + DEEP_NTH * u;
                 const int kr = e / wq, cq = e - kr * wq;
-                if (kr < kw) {
+                if (kr < kw && (u < 2 || u < wu_n)) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) Wt[(4 * cq + c) * WS + kr] = wreg[u][c];
                 }
@@ -942,7 +946,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         }
         __syncthreads();
         if (hh == 0) DEEP_STAMP(3);
-        // ---- this wave: query tile qt, key tiles kp, kp + 4 (nkt <= 8)
+        // ---- this wave: query tile qt, key tiles kp, kp + KPS (nkt <= 8: with one query tile per workgroup the second is always past the end)
         float qreg[NDT][4];
 #pragma unroll
         for (int u = 0; u < NDT; ++u) {
@@ -955,7 +959,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         float m = -INFINITY;
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
-            const int kt = kp + 4 * w;
+            const int kt = kp + KPS * w;
             f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
             if (kt < nkt) {
 #pragma unroll
@@ -994,7 +998,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         for (int o = 0; o < NDT; ++o) oacc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
-            const int kt = kp + 4 * w;
+            const int kt = kp + KPS * w;
             if (kt < nkt) {
 #pragma unroll
                 for (int o = 0; o < NDT; ++o) {
@@ -1014,23 +1018,24 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         if (hh == 0) DEEP_STAMP(4);
         __syncthreads();
         if (hh == 0) DEEP_STAMP(5);
-        // ---- merge the four key parts of every query: thread -> (query row, d quad)
-        for (int e = tid; e < 32 * QPR; e += DEEP_NTH) {
+        // ---- merge the KPS key parts of every query: thread -> (query row, d quad)
+        for (int e = tid; e < QR * QPR; e += DEEP_NTH) {
             const int qr = e / QPR, dq = e - qr * QPR;
             const int tq = qr >> 4, jq = qr & 15;
-            float mm[4], ll[4], M = -INFINITY;
+            float mm[8], ll[8], M = -INFINITY;
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                const int w = tq + 2 * k2;
-                mm[k2] = ml[(w * 16 + jq) * 2];
-                ll[k2] = ml[(w * 16 + jq) * 2 + 1];
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const int w = tq + QT * (k2 < KPS ? k2 : 0);
+                mm[k2] = k2 < KPS ? ml[(w * 16 + jq) * 2] : -INFINITY;
+                ll[k2] = k2 < KPS ? ml[(w * 16 + jq) * 2 + 1] : 0.f;
                 M = fmaxf(M, mm[k2]);
             }
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             float lt = 0.f;
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                const int w = tq + 2 * k2;
+            for (int k2 = 0; k2 < 8; ++k2) {
+                if (k2 >= KPS) break;                                     // (uniform)
+                const int w = tq + QT * k2;
                 const float f = mm[k2] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mm[k2] - M);
                 lt += ll[k2] * f;
                 o += *reinterpret_cast<const f32x4*>(Os + ((size_t)w * 16 + jq) * (D + 4) + 4 * dq) * f;
@@ -1040,10 +1045,10 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         __syncthreads();
     }
     DEEP_STAMP(6);
-    // ---- proj: [32 rows][NC cols] = Att [32][kw] x Wt^T; wave -> (tile, K part)
-    const int nct = NC >> 4, ntile = 2 * nct, kparts = 8 / ntile;       // (ntile 2 or 4)
+    // ---- proj: [QR rows][NC cols] = Att [QR][kw] x Wt^T; wave -> (tile, K part)
+    const int nct = NC >> 4, ntile = QT * nct, kparts = 8 / ntile;      // (ntile 1, 2 or 4)
     const int tile = wave % ntile, kpart = wave / ntile;
-    const int rt = tile & 1, ct = tile >> 1;
+    const int rt = QT == 2 ? (tile & 1) : 0, ct = QT == 2 ? (tile >> 1) : tile;
     const int kchunks = kw >> 4, cpp = (kchunks + kparts - 1) / kparts;  // 16-channel chunks per K part
     f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
     for (int cc = kpart * cpp; cc < (kpart + 1) * cpp && cc < kchunks; ++cc) {
@@ -1069,11 +1074,11 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(a.fin.gran, 0, tg ? (int)a.fin.gran_bytes : 0, 0x00020000);
     const unsigned slice_gran = (unsigned)((size_t)a.B * L * C);
     // epilogue: thread -> (row, column quad); K parts summed in order; head group 0 adds bias + residual
-    for (int e = tid; e < 32 * (NC >> 2); e += DEEP_NTH) {
+    for (int e = tid; e < QR * (NC >> 2); e += DEEP_NTH) {
         const int rr = e / (NC >> 2), cq = e - rr * (NC >> 2);
         const int tok = q0 + rr;
         if (tok >= L) continue;
-        const int t2 = (rr >> 4) + 2 * ((4 * cq) >> 4);        // tile of this quad
+        const int t2 = (rr >> 4) + QT * ((4 * cq) >> 4);       // tile of this quad
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         for (int k2 = 0; k2 < kparts; ++k2)
             v += *reinterpret_cast<const f32x4*>(Os + (size_t)(t2 + ntile * k2) * 16 * 20 + (rr & 15) * 20 + ((4 * cq) & 15));
@@ -1101,7 +1106,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         // ---- in-launch completion over the head groups (the K slices of the projection)
         float* scratch = Os + 8 * 16 * 20;                       // past the proj partials
         if (deep_fin_arrive(a.fin, (b * a.nqg + qg) * a.ncg + cg, a.nhg, scratch, tid)) {
-            for (int e = tid; e < 32 * (NC >> 2); e += DEEP_NTH) {
+            for (int e = tid; e < QR * (NC >> 2); e += DEEP_NTH) {
                 const int rr = e / (NC >> 2), cq = e - rr * (NC >> 2);
                 const int tok = q0 + rr, n = cg * NC + 4 * cq;
                 if (tok >= L) continue;
@@ -2096,7 +2101,8 @@ hipError_t launch_deep_repack(const float* W, int ldw, float* dst, const DeepArg
 static size_t deep_attn_smem(const DeepAttnArgs& a, int D) {
     const int KSTR = D + 4, VSTR = a.kcap + 4, AS = a.HPW * D + 8, WS = a.HPW * D + 4;
     const int os = 8 * 16 * (D + 4) > 8 * 16 * 20 + DEEP_FIN_FLOATS ? 8 * 16 * (D + 4) : 8 * 16 * 20 + DEEP_FIN_FLOATS;   // key-part partials | proj partials + completion scratch
-    return (size_t)(a.kcap * KSTR + D * VSTR + 32 * KSTR + 32 * AS + a.NC * WS + os + 8 * 16 * 2) * 4;
+    const int QR = 16 * (a.QT == 1 ? 1 : 2);
+    return (size_t)(a.kcap * KSTR + D * VSTR + QR * KSTR + QR * AS + a.NC * WS + os + 8 * 16 * 2) * 4;
 }
 
 bool deep_attn_configure(DeepAttnArgs& a) {
@@ -2104,13 +2110,18 @@ bool deep_attn_configure(DeepAttnArgs& a) {
     const int d = a.C / a.H;
     if (d != 16 && d != 32 && d != 64) return false;
     a.kcap = (a.L + 15) / 16 * 16;
-    a.nqg = (a.L + 31) / 32;
+    // round 6: ONE query tile per workgroup x 8 key parts, proj slices up to 64 columns -- at [128 x 512] 8 query groups x 4 head groups x 8 column groups = the same
+    // 256 workgroups, each recomputing half the attention (1.9482 -> 1.9385 ms per step same-box, profiles/r06_deep_attn_query_tile_ab.txt).  MTV_DEEP_ATTN_QT=2: round 4's
+    // 2 query tiles x 4 key parts, 16- / 32-column slices
+    static const int env_qt = getenv("MTV_DEEP_ATTN_QT") ? atoi(getenv("MTV_DEEP_ATTN_QT")) : 1;
+    a.QT = env_qt == 2 ? 2 : 1;
+    a.nqg = (a.L + 16 * a.QT - 1) / (16 * a.QT);
     // head group = K slice of the projection = an output slab: as few slabs as the grid allows (consumers re-read every slab)
     for (int hpw : {8, 4, 2, 1}) {
         if (a.H % hpw || hpw * d > 128) continue;
-        for (int nc : {32, 16}) {
-            if (a.C % nc) continue;
-            if ((hpw * d) * (nc / 4) > 2 * DEEP_NTH) continue;             // proj slice: two 16-byte quads per thread
+        for (int nc : {64, 32, 16}) {
+            if (a.C % nc || (nc == 64 && a.QT != 1)) continue;
+            if ((hpw * d) * (nc / 4) > (nc == 64 ? 4 : 2) * DEEP_NTH) continue;             // proj slice: two (NC = 64: four) 16-byte quads per thread
             a.HPW = hpw; a.NC = nc; a.nhg = a.H / hpw; a.ncg = a.C / nc;
             if (a.nhg > 8 || (a.nhg & (a.nhg - 1))) continue;
             if (deep_attn_smem(a, d) > 160 * 1024) continue;
@@ -2134,7 +2145,8 @@ hipError_t launch_deep_attn(const DeepAttnArgs& a0, hipStream_t s) {
     a.nslots = a.B * a.nqg * a.nhg;
     a.inv_nslots = 1.0f / (float)a.nslots;
     const size_t smem = deep_attn_smem(a, d);
-    if (smem > 160 * 1024 || (a.NC != 16 && a.NC != 32) || !(a.res.ks >= 1 && a.res.ks <= 8)) return hipErrorInvalidValue;
+    if (a.QT != 1 && a.QT != 2) return hipErrorInvalidValue;
+    if (smem > 160 * 1024 || (a.NC != 16 && a.NC != 32 && !(a.NC == 64 && a.QT == 1)) || !(a.res.ks >= 1 && a.res.ks <= 8)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(a.ncg * a.nslots));
     if (d == 16) hipLaunchKernelGGL((k_deep_attn<16>), grid, dim3(DEEP_NTH), smem, s, a);
     else if (d == 32) hipLaunchKernelGGL((k_deep_attn<32>), grid, dim3(DEEP_NTH), smem, s, a);

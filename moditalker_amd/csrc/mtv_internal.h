@@ -384,8 +384,10 @@ struct DeepAttnArgs {
     DeepSrc res;             // the block's input x (residual), possibly slabs
     float* out;              // slab 0 of [H / HPW][B][L][C]
     unsigned out_slab_stride;
-    int HPW, NC;             // heads per workgroup (K slice = HPW d channels), output columns per workgroup (16 or 32)
-    int nhg, nqg, ncg;       // head groups, query groups (32 rows), column groups
+    int HPW, NC;             // heads per workgroup (K slice = HPW d channels), output columns per workgroup (16 or 32; 64 with QT = 1)
+    int nhg, nqg, ncg;       // head groups, query groups (16 QT rows), column groups
+    int QT;                  // query tiles (16 rows) per workgroup: 2 = 2 query tiles x 4 key parts (round 4), 1 = 1 query tile x 8 key parts (round 6: half the
+                             // recomputed attention per workgroup, 64-column proj slices)
     int kcap;                // key capacity of the LDS tiles: 16 ceil(L / 16)
     float inv_nslots;
     int nslots;              // B * nqg * nhg
