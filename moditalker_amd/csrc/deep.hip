@@ -852,6 +852,11 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     }
     const int nk = k1 - k0, nkt = (nk + 15) >> 4;
     const int VSTR = a.kcap + 4, AS = HPW * D + 8, WS = HPW * D + 4;
+    // V^T bank swizzle (round 6): thread (key, d quad) writes V^T[4 qd + c][key] -- with d / 4 = 8 or 16 quads per key the lanes of a wave that differ only in qd >> 1 hit the
+    // same bank (VSTR = 4 mod 32: bank = 16 (qd & 1) + 4 c + key), a 4- / 8-way conflict on every one of the 16 scalar stores per thread and head: 60 % of this kernel's LDS-active
+    // cycles were conflict re-issues (profiles/r06_lds_bank_conflicts.txt).  The 4-key block index of a row is XORed with (qd >> 1) & 7 (rows 8 s .. 8 s + 7 of V^T share s): two lanes per
+    // bank, the minimum; keys stay contiguous inside a block, so the fragment reads remain 16-byte reads.  Needs whole 32-key groups: an even number of key tiles.
+    const int vswz = (nkt & 1) ? 0 : 7;
     float* const Ks = smem;                                   // [kcap][KSTR]
     float* const Vt = Ks + a.kcap * KSTR;                     // [D][VSTR]
     float* const Qs = Vt + D * VSTR;                          // [QR][KSTR]
@@ -917,8 +922,9 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
                 const bool in = key < nk;                                // rows past the last key of a tile are zero
                 const f32x4 kv = in ? kreg[u] * a.scale : f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(Ks + key * KSTR + 4 * qd) = kv;
+                const int keys = key ^ (((qd >> 1) & vswz) << 2);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) Vt[(4 * qd + c) * VSTR + key] = in ? vreg[u][c] : 0.f;
+                for (int c = 0; c < 4; ++c) Vt[(4 * qd + c) * VSTR + keys] = in ? vreg[u][c] : 0.f;
             }
         }
         if (tid < QR * QPR) {
@@ -1002,7 +1008,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
             if (kt < nkt) {
 #pragma unroll
                 for (int o = 0; o < NDT; ++o) {
-                    const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (16 * o + j) * VSTR + 16 * kt + 4 * g);
+                    const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (16 * o + j) * VSTR + 4 * ((4 * kt + g) ^ ((2 * o + (j >> 3)) & vswz)));
 #pragma unroll
                     for (int sI = 0; sI < 4; ++sI) oacc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[sI], st[w][sI], oacc[o], 0, 0, 0);
                 }
