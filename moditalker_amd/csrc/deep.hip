@@ -938,6 +938,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     for (int hh = 0; hh < HPW; ++hh) {
         park();
         if (hh == 0) DEEP_STAMP(2);
+        if (hh == 1) DEEP_STAMP(10);
         if (hh + 1 < HPW) issue(hh + 1);
         if (hh == 0) {
 #pragma unroll
@@ -952,6 +953,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
         }
         __syncthreads();
         if (hh == 0) DEEP_STAMP(3);
+        if (hh == 1) DEEP_STAMP(11);
         // ---- this wave: query tile qt, key tiles kp, kp + KPS (nkt <= 8: with one query tile per workgroup the second is always past the end)
         float qreg[NDT][4];
 #pragma unroll
@@ -1022,8 +1024,10 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
             if (g == 0) { ml[(wave * 16 + j) * 2] = m; ml[(wave * 16 + j) * 2 + 1] = lsum; }
         }
         if (hh == 0) DEEP_STAMP(4);
+        if (hh == 1) DEEP_STAMP(12);
         __syncthreads();
         if (hh == 0) DEEP_STAMP(5);
+        if (hh == 1) DEEP_STAMP(13);
         // ---- merge the KPS key parts of every query: thread -> (query row, d quad)
         for (int e = tid; e < QR * QPR; e += DEEP_NTH) {
             const int qr = e / QPR, dq = e - qr * QPR;
