@@ -857,6 +857,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     // cycles were conflict re-issues (profiles/r06_lds_bank_conflicts.txt).  The 4-key block index of a row is XORed with (qd >> 1) & 7 (rows 8 s .. 8 s + 7 of V^T share s): two lanes per
     // bank, the minimum; keys stay contiguous inside a block, so the fragment reads remain 16-byte reads.  Needs whole 32-key groups: an even number of key tiles.
     const int vswz = (nkt & 1) ? 0 : 7;
+    const int wswz = ((HPW * D) & 31) ? 0 : 7;                // ... and of the transposed proj slice Wt[column][k] (whole 32-k groups)
     float* const Ks = smem;                                   // [kcap][KSTR]
     float* const Vt = Ks + a.kcap * KSTR;                     // [D][VSTR]
     float* const Qs = Vt + D * VSTR;                          // [QR][KSTR]
@@ -946,8 +947,9 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
                 const int e = tid + DEEP_NTH * u;
                 const int kr = e / wq, cq = e - kr * wq;
                 if (kr < kw && (u < 2 || u < wu_n)) {
+                    const int krs = kr ^ (((cq >> 1) & wswz) << 2);              // (the V^T swizzle, for the same transposing store: row stride = 4 mod 32)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) Wt[(4 * cq + c) * WS + kr] = wreg[u][c];
+                    for (int c = 0; c < 4; ++c) Wt[(4 * cq + c) * WS + krs] = wreg[u][c];
                 }
             }
         }
@@ -1063,7 +1065,7 @@ __global__ __launch_bounds__(DEEP_NTH) void k_deep_attn(const DeepAttnArgs a) {
     f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
     for (int cc = kpart * cpp; cc < (kpart + 1) * cpp && cc < kchunks; ++cc) {
         const f32x4 af = *reinterpret_cast<const f32x4*>(Att + (16 * rt + j) * AS + 16 * cc + 4 * g);
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(Wt + (16 * ct + j) * WS + 16 * cc + 4 * g);
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(Wt + (16 * ct + j) * WS + 4 * ((4 * cc + g) ^ ((2 * ct + (j >> 3)) & wswz)));
 #pragma unroll
         for (int sI = 0; sI < 4; ++sI) pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[sI], bf[sI], pacc, 0, 0, 0);
     }
