@@ -317,6 +317,13 @@ def main():
                 launches=deep["launches"], algorithmic_bytes_per_step=deep["bytes"], ms_per_step=round(deep["ms"], 4),
                 achieved_GBs=round(deep["bytes"] / (deep["ms"] * 1e-3) / 1e9, 1),
                 frac=round(deep["bytes"] / (deep["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            # ... and the family's own counter row (committed PMC passes of the k_deep_conv launches alone, tools/pmc_util.py) over THIS run's family time
+            ed = pmc.get("k_deep_conv_only")
+            if ed and "fetch_raw_MB_per_step" in ed:
+                cb = (2.0 * ed["fetch_raw_MB_per_step"] + ed["write_raw_MB_per_step"]) * 1e6
+                roofline["hbm_view"]["deep_levels"].update(
+                    counter_bytes_per_step=round(cb), counter_GBs=round(cb / (deep["ms"] * 1e-3) / 1e9, 1),
+                    counter_over_algorithmic=round(cb / deep["bytes"], 3) if deep["bytes"] else None, counter_kind="committed")
             roofline["hbm_view"]["headline"] = "deep_levels"
         families = {k: dict(ms_per_step=round(v["ms"], 4), launches=v["launches"],
                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] else None)

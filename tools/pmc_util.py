@@ -75,6 +75,11 @@ for k, f in sorted(fam.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))
     out[k] = dict(launches_per_step=round(f["n"] / ns), mfma_util_eager=round(util, 4), coexec_over_mfma_busy=round(co, 4),
                   mfma_busy_cycles_per_step=round(f["SQ_VALU_MFMA_BUSY_CYCLES"] / ns), mfma_insts_per_step=round(f["SQ_INSTS_MFMA"] / ns))
 if a.fetch and a.write and a.trace:
+    DEEP = "k_deep_conv_only"          # the weight-streaming convs of the <= 128-token levels on their own (also part of the k_conv family)
+
+    def is_deep(name):
+        return name.split("(")[0].replace("void ", "").replace("mtv::", "").startswith("k_deep_conv")
+
     def per_family(path):
         rows = list(csv.DictReader(open(path)))
         acc = collections.defaultdict(float)
@@ -82,14 +87,20 @@ if a.fetch and a.write and a.trace:
         for st in sts:
             for r in st:
                 acc[fam_of(r["Kernel_Name"])] += float(r["Counter_Value"]) * 1024.0
+                if is_deep(r["Kernel_Name"]):
+                    acc[DEEP] += float(r["Counter_Value"]) * 1024.0
         return {k: v / len(sts) for k, v in acc.items()}
     F, W = per_family(a.fetch), per_family(a.write)
     rows = list(csv.DictReader(open(a.trace)))
     sts = step_rows(rows, lambda r: int(r["Start_Timestamp"]), a.launches)
     T = collections.defaultdict(float)
+    NL = collections.defaultdict(int)
     for st in sts:
         for r in st:
             T[fam_of(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+            if is_deep(r["Kernel_Name"]):
+                T[DEEP] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+                NL[DEEP] += 1
     print("# counter-based HBM-side traffic: (2 x FETCH_SIZE + WRITE_SIZE) / family time of the kernel trace (graph replay)")
     for k in sorted(F, key=lambda k: -F[k]):
         if k not in T or T[k] <= 0:
@@ -99,6 +110,8 @@ if a.fetch and a.write and a.trace:
         print(f"  {k:14s} FETCH {F[k] / 1e6:8.1f} MB  WRITE {W.get(k, 0) / 1e6:7.1f} MB  time {t * 1e6:8.1f} us/step  -> {b / t / 1e9:8.1f} GB/s")
         out.setdefault(k, {}).update(fetch_raw_MB_per_step=round(F[k] / 1e6, 1), write_raw_MB_per_step=round(W.get(k, 0) / 1e6, 1),
                                      ms_per_step_trace=round(t * 1e3, 4), hbm_counter_GBs=round(b / t / 1e9, 1))
+        if k == DEEP:
+            out[k]["launches_per_step"] = round(NL[DEEP] / len(sts))
         if "mfma_busy_cycles_per_step" in out[k]:      # matrix-pipe busy cycles (all SIMDs) over the SIMD-cycles of the family's graph-replay time at 2.4 GHz
             out[k]["mfma_util"] = round(out[k]["mfma_busy_cycles_per_step"] / (t * 2.4e9 * 1024), 4)
             print(f"  {k:14s} matrix-pipe busy / (kernel-trace family time x 2.4 GHz x 1024 SIMDs) = {out[k]['mfma_util']:.3f}")

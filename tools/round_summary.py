@@ -40,7 +40,8 @@ if b:
     print(f"| `gpu_active_s` | {b.get('gpu_active_s')} |")
     hv = (r.get("hbm_view") or {}).get("deep_levels")
     if hv:
-        print(f"| `roofline.hbm_view.deep_levels` | {hv['achieved_GBs']} GB/s algorithmic = **{hv['frac']}** of 8 TB/s over {hv['launches']} k_deep_conv launches ({hv['ms_per_step']} ms per step) |")
+        ctr = f"; counter side {hv['counter_GBs']} GB/s = {hv['counter_over_algorithmic']} x the algorithmic bytes" if hv.get("counter_GBs") else ""
+        print(f"| `roofline.hbm_view.deep_levels` | {hv['achieved_GBs']} GB/s algorithmic = **{hv['frac']}** of 8 TB/s over {hv['launches']} k_deep_conv launches ({hv['ms_per_step']} ms per step){ctr} |")
     r6 = b.get("res64_info")
     if r6:
         print(f"| `res64_info` (configs[3], informational) | {r6['steps_per_s']} steps/s, {r6['ms_per_step']} ms per step; conv {r6['conv_frac_of_f32_mfma_peak']} / attention {r6['attention_frac_of_f32_mfma_peak']} of the f32-MFMA peak |")

@@ -17,7 +17,7 @@ doc["source"] = ("rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE,
                  "(gfx950 reports 1/2 of wide streaming reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / "
                  "(family time of the graph-replay kernel trace x 2.4 GHz x 1024 SIMDs); not collected live; one entry per workload")
 out = dict(collected=sys.argv[2], commit=sys.argv[3] if len(sys.argv) > 3 else "")
-for k in ("k_conv", "k_attention"):
+for k in ("k_conv", "k_attention", "k_deep_conv_only"):
     if k in new and "fetch_raw_MB_per_step" in new[k]:
         out[k] = {f: new[k][f] for f in ("fetch_raw_MB_per_step", "write_raw_MB_per_step", "launches_per_step", "mfma_util", "mfma_insts_per_step", "ms_per_step_trace") if f in new[k]}
     elif k in prev:
